@@ -1,0 +1,188 @@
+/*
+ * sns.h -- C ABI of the MI355X-native stabilised Stokes / Navier-Stokes hot path.
+ *
+ * The reference (mungerct/Stabilized_Navier_Stokes_Flow_FEniCSx) has no FFI:
+ * its seam is the PETSc-SNES callback pair plus two driver functions in
+ * NavierStokes/NavierStokesChannelFlow.py.  Each entry point below replaces
+ * what DOLFINx/FFCx/PETSc do behind the cited reference lines; a maintainer
+ * binds them with the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures
+ *     (a HIP stream travels as void*).
+ *   - "_host" pointers are host memory, "_dev" pointers are device memory of
+ *     the GPU the handle was created on.  The caller owns every buffer it
+ *     passes; the handle owns mesh, BSR matrix, preconditioner and scratch.
+ *   - dof numbering: 4*node + c, c in {ux,uy,uz,p} (node-blocked P1-P1 mixed
+ *     space of create_boundary_conditions, :128-129).
+ *   - every function returns 0 on success, <0 on a hard error (SNS_E_*);
+ *     non-convergence is NOT an error (the reference prints the reason and
+ *     carries on, :297-298): it is reported through *reason, whose sign
+ *     convention follows PETSc (>0 converged, <0 diverged).
+ *   - calls are stream-ordered on the handle's stream and synchronous at
+ *     return unless stated otherwise.  With a communicator attached every call
+ *     is collective over all ranks (as every PETSc call at :288-293 is).
+ */
+#ifndef SNS_H
+#define SNS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sns_ctx* sns_handle;
+
+/* error codes */
+#define SNS_OK            0
+#define SNS_E_ARG        -1   /* bad argument / shape mismatch            */
+#define SNS_E_HIP        -2   /* HIP runtime error (see sns_last_error)   */
+#define SNS_E_STATE      -3   /* call order (e.g. solve before assemble)  */
+#define SNS_E_MESH       -4   /* degenerate / inverted input mesh         */
+#define SNS_E_COMM       -5   /* RCCL error                               */
+
+/* weak forms */
+#define SNS_FORM_STOKES   0   /* setup_stokes_weak_form      :160-172 */
+#define SNS_FORM_NS       1   /* define_navier_stokes_form   :220-251 */
+
+/* Krylov methods (snes_ksp_type :77, petsc_options :198-202) */
+#define SNS_KSP_BICGSTAB  0
+#define SNS_KSP_FGMRES    1
+
+/* preconditioners */
+#define SNS_PC_NONE       0
+#define SNS_PC_BJACOBI    1   /* 4x4 nodal block Jacobi                               */
+#define SNS_PC_AMG        2   /* aggregation AMG, block-Jacobi smoothing (per-rank)   */
+
+/* converged reasons (PETSc numbering, so logs read like the reference's) */
+#define SNS_KSP_CONVERGED_RTOL        2
+#define SNS_KSP_CONVERGED_ATOL        3
+#define SNS_KSP_DIVERGED_ITS         -3
+#define SNS_KSP_DIVERGED_BREAKDOWN   -5
+#define SNS_KSP_DIVERGED_NANORINF    -9
+#define SNS_SNES_CONVERGED_FNORM_ABS        2
+#define SNS_SNES_CONVERGED_FNORM_RELATIVE   3
+#define SNS_SNES_CONVERGED_SNORM_RELATIVE   4
+#define SNS_SNES_DIVERGED_LINEAR_SOLVE     -3
+#define SNS_SNES_DIVERGED_FNORM_NAN        -4
+#define SNS_SNES_DIVERGED_MAX_IT           -5
+#define SNS_SNES_DIVERGED_LINE_SEARCH      -6
+
+/* solver knobs; sns_default_options() fills the reference's values */
+typedef struct {
+    double reynolds;        /* Re, nu = 1/Re                         :223            */
+    int    ksp_type;        /* SNS_KSP_*                             :77,:199        */
+    int    pc_type;         /* SNS_PC_*                              :200            */
+    double ksp_rtol;        /* 1e-8                                  :283            */
+    double ksp_atol;        /* 1e-50 (PETSc default)                                 */
+    int    ksp_max_it;      /* 10000 (PETSc default)                                 */
+    int    gmres_restart;   /* 30 (PETSc default)                                    */
+    double snes_rtol;       /* 1e-8                                  :281            */
+    double snes_atol;       /* 1e-8                                  :281            */
+    double snes_stol;       /* 1e-8 (PETSc default)                                  */
+    int    snes_max_it;     /* 30                                    :281            */
+    int    amg_max_levels;  /* 12                                                    */
+    int    amg_coarse_size; /* stop coarsening at <= this many nodes (dense solve)   */
+    int    amg_agg_size;    /* max nodes per aggregate (8)                           */
+    int    amg_nu;          /* pre = post smoothing sweeps (2)                       */
+    double amg_omega;       /* block-Jacobi damping (0.8)                            */
+    int    monitor;         /* 1: print ||r|| per Krylov/Newton iteration (ksp_monitor / snes_monitor :201,:276) */
+    int    corrected_convection; /* 0 = reference as written (dot(u,grad(.)) :241,:247); 1 = (u.grad)(.) */
+} sns_options;
+
+void sns_default_options(sns_options* opt);
+const char* sns_last_error(void);
+const char* sns_version(void);
+
+/* ---- setup: replaces gmshio.model_to_mesh + functionspace + create_matrix +
+ *      locate_dofs_topological/dirichletbc (:111,:127-147,:271-272) ----------
+ * points_host  [n_nodes*3]   vertex coordinates
+ * tets_host    [n_tets*4]    connectivity, cell-local vertex order PRESERVED
+ * bc_mask_host [4*n_nodes]   1 where the dof is Dirichlet-constrained
+ * bc_val_host  [4*n_nodes]   prescribed value g (ignored where mask==0)
+ * device       HIP device ordinal                                              */
+int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets,
+               const double* points_host, const int32_t* tets_host,
+               const uint8_t* bc_mask_host, const double* bc_val_host,
+               int device, const sns_options* opt);
+int sns_destroy(sns_handle h);
+int sns_set_stream(sns_handle h, void* hip_stream);
+int sns_set_options(sns_handle h, const sns_options* opt);
+int sns_get_options(sns_handle h, sns_options* opt);
+
+/* sizes: n_owned = rows this rank owns, n_local = owned + ghost nodes */
+int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,
+                  int64_t* n_tets, int64_t* nnz_blocks);
+
+/* ---- distributed setup (one process per GPU; RCCL over xGMI) ---------------
+ * Local mesh = owned nodes first [0,n_owned), ghost nodes after; tets = all
+ * tets touching an owned node (redundant ghost-tet assembly: no assembly
+ * communication, replaces F.ghostUpdate(ADD,REVERSE) :66 and MatAssembly :75).
+ * Neighbour k: we send the owned-node values listed in send_idx[send_ptr[k]..)
+ * and receive into ghost slots recv_idx[recv_ptr[k]..) (local node ids).
+ * nccl_unique_id: 128 bytes from sns_comm_unique_id on rank 0, broadcast by
+ * the caller (torch.distributed).                                             */
+int sns_comm_unique_id(char id_out[128]);
+int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_id[128],
+                    int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
+                    const int32_t* send_ptr, const int32_t* send_idx,
+                    const int32_t* recv_ptr, const int32_t* recv_idx);
+
+/* ---- hot path --------------------------------------------------------------*/
+/* NonlinearPDE_SNESProblem.F (:51-67): F(w) incl. lifting and F_B = w_B - g.
+ * form = SNS_FORM_NS, or SNS_FORM_STOKES for the linear residual A w - b.     */
+int sns_residual(sns_handle h, int form, const double* w_dev, double* F_dev);
+/* NonlinearPDE_SNESProblem.J (:69-75): assemble the Jacobian (BC rows+cols
+ * zeroed, unit diagonal) into the handle's BSR matrix; if F_dev != NULL the
+ * residual is produced by the same fused element pass.                        */
+int sns_jacobian(sns_handle h, int form, const double* w_dev, double* F_dev);
+/* MatMult with the assembled operator: y = A x (halo exchange inside).        */
+int sns_spmv(sns_handle h, const double* x_dev, double* y_dev);
+/* PCSetUp / PCApply for the current matrix.                                   */
+int sns_pc_setup(sns_handle h);
+int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
+/* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
+ * guess on entry.  rnorm = final true-residual 2-norm.                        */
+int sns_krylov_solve(sns_handle h, const double* b_dev, double* x_dev,
+                     int* its, int* reason, double* rnorm);
+/* solve_stokes_problem (:197-218): assemble + lift + KSP; U_dev receives U.   */
+int sns_stokes_solve(sns_handle h, double* U_dev, int* ksp_its, int* reason, double* rnorm);
+/* solve_navier_stokes (:268-312): SNES newtonls + bt; w_dev updated in place
+ * (snes.solve(None, w) :293).  fnorm_hist (nullable) gets ||F|| per iteration
+ * (snes_monitor :276), at most hist_cap entries.                              */
+int sns_newton_solve(sns_handle h, double* w_dev, int* its, int* reason,
+                     int* total_ksp_its, double* fnorm_hist, int hist_cap);
+
+/* ---- introspection (tests, profiling) --------------------------------------*/
+/* device pointers of the assembled BSR4 operator (block row-major 4x4)        */
+int sns_get_bsr(sns_handle h, int32_t* n_rows, int64_t* nnzb, const int32_t** rowptr_dev,
+                const int32_t** colind_dev, const double** vals_dev);
+/* element-level output of the last sns_jacobian call: Ke [n_tets][a][b][c][d]
+ * (16 blocks of 4x4) as produced by the element kernel before the gather.     */
+int sns_get_element_scratch(sns_handle h, const double** Ke_dev, const double** Fe_dev);
+/* copy an internal device array into a caller-owned device buffer of nbytes
+ * (exact size required): tests read the assembled operator through this.      */
+#define SNS_EXPORT_ROWPTR 0   /* int32 [n_local+1]        */
+#define SNS_EXPORT_COLIND 1   /* int32 [nnzb]             */
+#define SNS_EXPORT_VALS   2   /* double [nnzb*16]         */
+#define SNS_EXPORT_KE     3   /* double [n_tets*256]      */
+#define SNS_EXPORT_FE     4   /* double [n_tets*16]       */
+int sns_export(sns_handle h, int what, void* dst_dev, int64_t nbytes);
+/* timing of the phases of the last solve, milliseconds (HIP events)           */
+typedef struct {
+    double assemble_ms, pc_setup_ms, krylov_ms, spmv_ms_avg;
+    int64_t spmv_calls; int ksp_its; int amg_levels;
+} sns_timings;
+int sns_get_timings(sns_handle h, sns_timings* t);
+int sns_reset_timings(sns_handle h);
+/* raw kernel launchers for micro-benchmarks (bench.py roofline leg): run the
+ * kernel `reps` times between two HIP events on the handle's stream and return
+ * the average duration in ms.                                                  */
+int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
+int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNS_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of the C-ABI in include/sns.h (libsns.so, built in-tree by
+``__graft_entry__.build()`` / ``csrc/Makefile``).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing
+the solver raises.  torch is imported first so that libsns.so binds to the same
+HIP / RCCL runtime instances torch already loaded (same SONAMEs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsns.so")
+
+
+class SnsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"sns error {code}: {msg}")
+        self.code = code
+
+
+class SnsOptions(C.Structure):
+    """Mirror of ``sns_options`` (include/sns.h)."""
+    _fields_ = [
+        ("reynolds", C.c_double), ("ksp_type", C.c_int), ("pc_type", C.c_int),
+        ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double), ("ksp_max_it", C.c_int),
+        ("gmres_restart", C.c_int), ("snes_rtol", C.c_double), ("snes_atol", C.c_double),
+        ("snes_stol", C.c_double), ("snes_max_it", C.c_int), ("amg_max_levels", C.c_int),
+        ("amg_coarse_size", C.c_int), ("amg_agg_size", C.c_int), ("amg_nu", C.c_int),
+        ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int),
+    ]
+
+
+class SnsTimings(C.Structure):
+    _fields_ = [("assemble_ms", C.c_double), ("pc_setup_ms", C.c_double), ("krylov_ms", C.c_double),
+                ("spmv_ms_avg", C.c_double), ("spmv_calls", C.c_int64), ("ksp_its", C.c_int),
+                ("amg_levels", C.c_int)]
+
+
+# constants of sns.h
+FORM_STOKES, FORM_NS = 0, 1
+KSP_BICGSTAB, KSP_FGMRES = 0, 1
+PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2
+EXPORT_ROWPTR, EXPORT_COLIND, EXPORT_VALS, EXPORT_KE, EXPORT_FE = 0, 1, 2, 3, 4
+KSP_NAMES = {"bicgstab": KSP_BICGSTAB, "bcgs": KSP_BICGSTAB, "fgmres": KSP_FGMRES, "gmres": KSP_FGMRES}
+PC_NAMES = {"none": PC_NONE, "bjacobi": PC_BJACOBI, "jacobi": PC_BJACOBI, "amg": PC_AMG}
+
+# every symbol include/sns.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+_P = C.c_void_p
+_SIGNATURES = [
+    ("sns_default_options", None, [C.POINTER(SnsOptions)]),
+    ("sns_last_error", C.c_char_p, []),
+    ("sns_version", C.c_char_p, []),
+    ("sns_create", C.c_int, [C.POINTER(_H), C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int, C.POINTER(SnsOptions)]),
+    ("sns_destroy", C.c_int, [_H]),
+    ("sns_set_stream", C.c_int, [_H, _P]),
+    ("sns_set_options", C.c_int, [_H, C.POINTER(SnsOptions)]),
+    ("sns_get_options", C.c_int, [_H, C.POINTER(SnsOptions)]),
+    ("sns_get_sizes", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                C.POINTER(C.c_int64)]),
+    ("sns_comm_unique_id", C.c_int, [C.c_char_p]),
+    ("sns_attach_comm", C.c_int, [_H, C.c_int, C.c_int, C.c_char_p, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
+    ("sns_residual", C.c_int, [_H, C.c_int, _P, _P]),
+    ("sns_jacobian", C.c_int, [_H, C.c_int, _P, _P]),
+    ("sns_spmv", C.c_int, [_H, _P, _P]),
+    ("sns_pc_setup", C.c_int, [_H]),
+    ("sns_pc_apply", C.c_int, [_H, _P, _P]),
+    ("sns_krylov_solve", C.c_int, [_H, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    ("sns_stokes_solve", C.c_int, [_H, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    ("sns_newton_solve", C.c_int, [_H, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_double), C.c_int]),
+    ("sns_get_bsr", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(_P),
+                              C.POINTER(_P)]),
+    ("sns_get_element_scratch", C.c_int, [_H, C.POINTER(_P), C.POINTER(_P)]),
+    ("sns_export", C.c_int, [_H, C.c_int, _P, C.c_int64]),
+    ("sns_get_timings", C.c_int, [_H, C.POINTER(SnsTimings)]),
+    ("sns_reset_timings", C.c_int, [_H]),
+    ("sns_bench_spmv", C.c_int, [_H, _P, _P, C.c_int, C.POINTER(C.c_double)]),
+    ("sns_bench_assemble", C.c_int, [_H, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_double)]),
+]
+SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def load():
+    """dlopen libsns.so and type every entry point; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                          " (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in _SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise SnsError(rc, load().sns_last_error().decode())
+
+
+def default_options(**kw) -> SnsOptions:
+    o = SnsOptions()
+    load().sns_default_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "ksp_type" and isinstance(v, str):
+            v = KSP_NAMES[v]
+        if k == "pc_type" and isinstance(v, str):
+            v = PC_NAMES[v]
+        if not hasattr(o, k):
+            raise TypeError(f"unknown option {k}")
+        setattr(o, k, v)
+    return o

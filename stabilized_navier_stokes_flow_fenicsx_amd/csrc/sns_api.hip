@@ -1,0 +1,1080 @@
+// C-ABI layer (include/sns.h): context, assembly driver, operator hierarchy,
+// Krylov (BiCGStab / FGMRES) and Newton drivers.  Host code only launches
+// kernels from sns_kernels.hip and moves scalars; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "sns_internal.h"
+#include "sns_kernels.h"
+
+namespace sns {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" +         \
+                      std::to_string(__LINE__));                                                          \
+            return SNS_E_HIP;                                                                             \
+        }                                                                                                 \
+    } while (0)
+#define NCCL_TRY(expr)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t _e = (expr);                                                                         \
+        if (_e != ncclSuccess) {                                                                          \
+            set_error(std::string(#expr) + ": " + ncclGetErrorString(_e));                                \
+            return SNS_E_COMM;                                                                            \
+        }                                                                                                 \
+    } while (0)
+#define SNS_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        int _r = (expr);                                                                                  \
+        if (_r != SNS_OK) return _r;                                                                      \
+    } while (0)
+
+template <class T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    return SNS_OK;
+}
+template <class T>
+static int dev_upload(T** p, const std::vector<T>& v, hipStream_t) {
+    SNS_TRY(dev_alloc(p, v.size()));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SNS_OK;
+}
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    std::vector<int> nbr;
+    std::vector<int32_t> send_ptr, recv_ptr;     // host copies (counts in nodes)
+    int32_t *send_idx = nullptr, *recv_idx = nullptr;
+    double *send_buf = nullptr, *recv_buf = nullptr;
+};
+
+}  // namespace sns
+
+using namespace sns;
+
+struct sns_ctx {
+    sns_options opt;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // mesh
+    int32_t n = 0, n_owned = 0;
+    int64_t E = 0;
+    int32_t* tets = nullptr;
+    double* pts = nullptr;
+    uint8_t* bc_mask = nullptr;
+    double* bc_val = nullptr;
+    // assembly maps
+    int64_t *nt_ptr = nullptr, *c_ptr = nullptr;
+    int32_t *nt_idx = nullptr, *c_idx = nullptr;
+    double *Ke = nullptr, *Fe = nullptr;
+    // operator hierarchy; levels[0] is the assembled fine operator
+    std::vector<Level> levels;
+    std::vector<int32_t*> slot_row;              // per level
+    std::vector<uint8_t*> empty_c;               // per level (coarse side), level l -> empty flags of level l+1
+    std::vector<double*> pong;                   // per level smoother ping-pong buffer
+    int* d_piv = nullptr;
+    int* d_sing = nullptr;
+    bool has_matrix = false, pc_ready = false;
+    int matrix_form = -1;
+    // reductions
+    double* partial = nullptr;                   // [2048*8]
+    double* d_scal = nullptr;                    // [256]
+    double* h_scal = nullptr;                    // pinned [256]
+    // Krylov workspace
+    std::vector<double*> kv;                     // allocated vectors (4*n each)
+    double* gm_V = nullptr;                      // (m+1) * ld
+    double* gm_Z = nullptr;                      // m * ld
+    int gm_m = 0;
+    double* d_h = nullptr;                       // device Hessenberg column scratch [3*(m+2)]
+    // Newton workspace
+    double *nw_F = nullptr, *nw_y = nullptr, *nw_w = nullptr, *nw_t = nullptr;
+    sns_timings tm{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unique_ptr<Comm> comm;
+    std::unique_ptr<HostPattern> pattern;      // kept until the (lazy) hierarchy build
+};
+
+namespace {
+
+inline int vec_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+inline int64_t ld_of(const sns_ctx* h) { return 4 * (int64_t)h->n; }
+inline int64_t nred_of(const sns_ctx* h) { return 4 * (int64_t)h->n_owned; }
+
+int sync_stream(sns_ctx* h) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SNS_OK;
+}
+
+// finish a two-stage reduction: partial[nblocks][nred] -> dst_dev[0..nred) (+ all-reduce over ranks)
+int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
+    hipLaunchKernelGGL(k_reduce_final, dim3(nred), dim3(256), 0, h->stream, nblocks, nred, h->partial, dst_dev);
+    if (h->comm && h->comm->nranks > 1)
+        NCCL_TRY(ncclAllReduce(dst_dev, dst_dev, nred, ncclDouble, ncclSum, h->comm->comm, h->stream));
+    return SNS_OK;
+}
+// ... and bring `count` doubles starting at src_dev to the host (synchronises the stream)
+int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
+    HIP_TRY(hipMemcpyAsync(h->h_scal, src_dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(out, h->h_scal, count * sizeof(double));
+    return SNS_OK;
+}
+
+int halo_exchange(sns_ctx* h, double* x) {
+    Comm* c = h->comm.get();
+    if (!c || c->nranks <= 1 || c->nbr.empty()) return SNS_OK;
+    const int nn = (int)c->nbr.size();
+    const int32_t ns = c->send_ptr[nn], nr = c->recv_ptr[nn];
+    if (ns > 0)
+        hipLaunchKernelGGL(k_pack, dim3((4 * (int64_t)ns + 255) / 256), dim3(256), 0, h->stream, ns, c->send_idx, x,
+                           c->send_buf);
+    NCCL_TRY(ncclGroupStart());
+    for (int k = 0; k < nn; ++k) {
+        const int32_t s0 = c->send_ptr[k], s1 = c->send_ptr[k + 1];
+        const int32_t r0 = c->recv_ptr[k], r1 = c->recv_ptr[k + 1];
+        if (s1 > s0)
+            NCCL_TRY(ncclSend(c->send_buf + 4 * (int64_t)s0, 4 * (size_t)(s1 - s0), ncclDouble, c->nbr[k], c->comm,
+                              h->stream));
+        if (r1 > r0)
+            NCCL_TRY(ncclRecv(c->recv_buf + 4 * (int64_t)r0, 4 * (size_t)(r1 - r0), ncclDouble, c->nbr[k], c->comm,
+                              h->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    if (nr > 0)
+        hipLaunchKernelGGL(k_unpack, dim3((4 * (int64_t)nr + 255) / 256), dim3(256), 0, h->stream, nr, c->recv_idx,
+                           c->recv_buf, x);
+    return SNS_OK;
+}
+
+// y = A_l x (or fused variants).  rows = number of block rows computed.
+template <int MODE>
+void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
+                 double omega, const double* dotw) {
+    const int grid = (rows + 31) / 32;
+    if (grid == 0) return;
+    hipLaunchKernelGGL((k_spmv<MODE>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y,
+                       b, L.dinv, omega, dotw, h->partial);
+}
+
+int alloc_level_vectors(Level& L) {
+    const size_t nd = 4 * (size_t)L.n;
+    SNS_TRY(dev_alloc(&L.x, nd));
+    SNS_TRY(dev_alloc(&L.b, nd));
+    SNS_TRY(dev_alloc(&L.r, nd));
+    HIP_TRY(hipMemset(L.x, 0, nd * sizeof(double)));
+    HIP_TRY(hipMemset(L.b, 0, nd * sizeof(double)));
+    HIP_TRY(hipMemset(L.r, 0, nd * sizeof(double)));
+    return SNS_OK;
+}
+
+int upload_pattern(Level& L, const HostPattern& P, int32_t** slot_row, hipStream_t s) {
+    L.n = P.n;
+    L.nnzb = P.nnzb;
+    SNS_TRY(dev_upload(&L.rowptr, P.rowptr, s));
+    SNS_TRY(dev_upload(&L.colind, P.colind, s));
+    SNS_TRY(dev_upload(&L.diag, P.diag, s));
+    SNS_TRY(dev_alloc(&L.vals, (size_t)P.nnzb * 16));
+    SNS_TRY(dev_alloc(&L.dinv, (size_t)P.n * 16));
+    SNS_TRY(dev_alloc(slot_row, (size_t)P.nnzb));
+    hipLaunchKernelGGL(k_fill_slot_row, dim3((P.n + 255) / 256), dim3(256), 0, s, P.n, L.rowptr, *slot_row);
+    return SNS_OK;
+}
+
+// Build the aggregation hierarchy (symbolic, once per mesh).
+int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
+    const sns_options& o = h->opt;
+    HostPattern cur = fine;
+    int32_t n_active = h->n_owned;
+    for (int l = 0; l + 1 < o.amg_max_levels; ++l) {
+        if (n_active <= o.amg_coarse_size) break;
+        HostAggregation A;
+        build_aggregation_active(cur, n_active, std::max(2, o.amg_agg_size), A);
+        if (A.nc >= n_active || A.nc == 0) break;              // no progress
+        Level& L = h->levels[l];
+        L.nc = A.nc;
+        SNS_TRY(dev_upload(&L.agg, A.agg, h->stream));
+        SNS_TRY(dev_upload(&L.m_ptr, A.m_ptr, h->stream));
+        SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
+        SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
+        SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+        h->levels.emplace_back();
+        h->slot_row.push_back(nullptr);
+        h->empty_c.push_back(nullptr);
+        h->pong.push_back(nullptr);
+        Level& C = h->levels.back();
+        SNS_TRY(upload_pattern(C, A.coarse, &h->slot_row.back(), h->stream));
+        C.n_owned = C.n;
+        SNS_TRY(alloc_level_vectors(C));
+        SNS_TRY(dev_alloc(&h->pong.back(), 4 * (size_t)C.n));
+        HIP_TRY(hipMemset(h->pong.back(), 0, 4 * (size_t)C.n * sizeof(double)));
+        if (l == 0) {
+            SNS_TRY(dev_alloc(&h->empty_c[0], 4 * (size_t)A.nc));
+            hipLaunchKernelGGL(k_empty_coarse, dim3((4 * (int64_t)A.nc + 255) / 256), dim3(256), 0, h->stream,
+                               A.nc, L.m_ptr, L.m_idx, L.free_mask, h->empty_c[0]);
+        }
+        cur = std::move(A.coarse);
+        n_active = cur.n;
+    }
+    Level& last = h->levels.back();
+    if (h->levels.size() > 1 && last.n <= std::max(o.amg_coarse_size, 40)) {
+        const size_t N = 4 * (size_t)last.n;
+        SNS_TRY(dev_alloc(&last.dense_inv, N * N));
+        SNS_TRY(dev_alloc(&h->d_piv, N));
+    }
+    h->tm.amg_levels = (int)h->levels.size();
+    return SNS_OK;
+}
+
+int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
+    if (form != SNS_FORM_STOKES && form != SNS_FORM_NS) { set_error("bad form"); return SNS_E_ARG; }
+    if (form == SNS_FORM_NS && !w) { set_error("NS form needs a state vector"); return SNS_E_ARG; }
+    if (want_matrix && !h->Ke) SNS_TRY(dev_alloc(&h->Ke, (size_t)h->E * 256));
+    if (!h->Fe) SNS_TRY(dev_alloc(&h->Fe, (size_t)h->E * 16));
+    const int grid = (int)((h->E + EL_TETS_PER_BLOCK - 1) / EL_TETS_PER_BLOCK);
+    const double nu = 1.0 / h->opt.reynolds;
+    double* Fe = F ? h->Fe : nullptr;
+    if (grid > 0) {
+        if (form == SNS_FORM_STOKES)
+            hipLaunchKernelGGL((k_element<SNS_FORM_STOKES, false>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+        else if (!h->opt.corrected_convection)
+            hipLaunchKernelGGL((k_element<SNS_FORM_NS, false>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+        else
+            hipLaunchKernelGGL((k_element<SNS_FORM_NS, true>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+    }
+    Level& L = h->levels[0];
+    if (want_matrix) {
+        const int64_t nth = L.nnzb * 16;
+        hipLaunchKernelGGL(k_gather_matrix, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.nnzb,
+                           h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->bc_mask, h->Ke, L.vals);
+        h->has_matrix = true;
+        h->pc_ready = false;
+        h->matrix_form = form;
+    }
+    if (F) {
+        const int64_t nth = 4 * (int64_t)h->n_owned;
+        hipLaunchKernelGGL(k_gather_residual, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream,
+                           h->n_owned, h->nt_ptr, h->nt_idx, h->bc_mask, h->bc_val, w, h->Fe, F);
+    }
+    HIP_TRY(hipGetLastError());
+    return SNS_OK;
+}
+
+// ---- preconditioner -----------------------------------------------------------
+int pc_setup(sns_ctx* h) {
+    if (!h->has_matrix) { set_error("pc_setup before a matrix was assembled"); return SNS_E_STATE; }
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    const int nl = (h->opt.pc_type == SNS_PC_AMG) ? (int)h->levels.size() : 1;
+    for (int l = 0; l < nl; ++l) {
+        Level& L = h->levels[l];
+        const int32_t rows = (l == 0) ? h->n_owned : L.n;
+        hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
+        if (l + 1 < nl) {
+            Level& C = h->levels[l + 1];
+            const int64_t nth = C.nnzb * 16;
+            hipLaunchKernelGGL(k_galerkin, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, C.nnzb,
+                               L.r_ptr, L.r_idx, h->slot_row[l], L.colind, L.free_mask, L.vals, h->slot_row[l + 1],
+                               C.colind, (l == 0) ? h->empty_c[0] : (const uint8_t*)nullptr, C.vals);
+        } else if (L.dense_inv && nl > 1) {
+            const int N = 4 * L.n;
+            HIP_TRY(hipMemsetAsync(L.dense_inv, 0, (size_t)N * N * sizeof(double), h->stream));
+            const int64_t nth = L.nnzb * 16;
+            hipLaunchKernelGGL(k_bsr_to_dense, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.n,
+                               L.rowptr, L.colind, L.vals, L.dense_inv);
+            hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(1024), 0, h->stream, N, L.dense_inv, h->d_piv,
+                               h->d_sing);
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->tm.pc_setup_ms += ms;
+    HIP_TRY(hipGetLastError());
+    h->pc_ready = true;
+    return SNS_OK;
+}
+
+// V-cycle on level l: x <- approx A_l^-1 b  (x overwritten; zero initial guess)
+int vcycle(sns_ctx* h, int l, const double* b, double* x) {
+    Level& L = h->levels[l];
+    const int32_t rows = (l == 0) ? h->n_owned : L.n;
+    const bool last = (l + 1 == (int)h->levels.size());
+    const double om = h->opt.amg_omega;
+    const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
+    if (last) {
+        if (L.dense_inv) {
+            const int N = 4 * L.n;
+            hipLaunchKernelGGL(k_dense_matvec, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_inv, b, x);
+            return SNS_OK;
+        }
+        // coarsest level too large for the dense solve: a fixed number of Jacobi sweeps (still a linear operator)
+        double* cur = x;
+        double* oth = h->pong[l];
+        hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+        for (int s = 0; s < 8; ++s) {       // even count: result ends in x
+            launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+            std::swap(cur, oth);
+        }
+        return SNS_OK;
+    }
+    const int nu = std::max(1, h->opt.amg_nu);
+    const int nswaps = 2 * nu - 1;
+    double* cur = (nswaps & 1) ? h->pong[l] : x;
+    double* oth = (nswaps & 1) ? x : h->pong[l];
+    hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+    for (int s = 1; s < nu; ++s) {
+        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+        std::swap(cur, oth);
+    }
+    launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, nullptr);
+    Level& C = h->levels[l + 1];
+    hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n + 255) / 256)), dim3(256), 0, h->stream, C.n,
+                       L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
+    SNS_TRY(vcycle(h, l + 1, C.b, C.x));
+    hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
+    for (int s = 0; s < nu; ++s) {
+        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+        std::swap(cur, oth);
+    }
+    // cur == x by construction of the start buffer
+    return SNS_OK;
+}
+
+int pc_apply(sns_ctx* h, const double* r, double* z) {
+    const int64_t nd = nred_of(h);
+    switch (h->opt.pc_type) {
+        case SNS_PC_NONE:
+            HIP_TRY(hipMemcpyAsync(z, r, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            return SNS_OK;
+        case SNS_PC_BJACOBI:
+            hipLaunchKernelGGL(k_bjacobi, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, h->stream, h->n_owned,
+                               h->levels[0].dinv, r, 1.0, z);
+            return SNS_OK;
+        case SNS_PC_AMG:
+            return vcycle(h, 0, r, z);
+    }
+    set_error("bad pc_type");
+    return SNS_E_ARG;
+}
+
+// operator apply with halo exchange (x must have room for the ghost tail)
+int op_apply(sns_ctx* h, double* x, double* y) {
+    SNS_TRY(halo_exchange(h, x));
+    launch_spmv<SPMV_AX>(h, h->levels[0], h->n_owned, x, y, nullptr, 0.0, nullptr);
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+int op_residual(sns_ctx* h, double* x, const double* b, double* r) {
+    SNS_TRY(halo_exchange(h, x));
+    launch_spmv<SPMV_B_MINUS_AX>(h, h->levels[0], h->n_owned, x, r, b, 0.0, nullptr);
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+
+int get_vec(sns_ctx* h, size_t k, double** out) {
+    while (h->kv.size() <= k) {
+        double* p = nullptr;
+        SNS_TRY(dev_alloc(&p, (size_t)ld_of(h)));
+        HIP_TRY(hipMemset(p, 0, (size_t)ld_of(h) * sizeof(double)));
+        h->kv.push_back(p);
+    }
+    *out = h->kv[k];
+    return SNS_OK;
+}
+
+int norm2(sns_ctx* h, const double* x, double* out) {
+    const int64_t nd = nred_of(h);
+    const int g = vec_grid(nd);
+    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, x, h->partial);
+    SNS_TRY(reduce_to(h, g, 2, h->d_scal));
+    double v[2];
+    SNS_TRY(fetch(h, h->d_scal, 2, v));
+    *out = std::sqrt(v[0]);
+    return SNS_OK;
+}
+int dot(sns_ctx* h, const double* x, const double* y, double* out) {
+    const int64_t nd = nred_of(h);
+    const int g = vec_grid(nd);
+    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, y, h->partial);
+    SNS_TRY(reduce_to(h, g, 2, h->d_scal));
+    double v[2];
+    SNS_TRY(fetch(h, h->d_scal, 2, v));
+    *out = v[0];
+    return SNS_OK;
+}
+
+// ---- BiCGStab (right-preconditioned; same recurrences as oracle/solve.py:bicgstab_bj) ----
+int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
+    const sns_options& o = h->opt;
+    const int64_t nd = nred_of(h);
+    const int g = vec_grid(nd);
+    double *r, *rhat, *p, *v, *s, *t, *ph, *sh;
+    SNS_TRY(get_vec(h, 0, &r)); SNS_TRY(get_vec(h, 1, &rhat)); SNS_TRY(get_vec(h, 2, &p));
+    SNS_TRY(get_vec(h, 3, &v)); SNS_TRY(get_vec(h, 4, &s)); SNS_TRY(get_vec(h, 5, &t));
+    SNS_TRY(get_vec(h, 6, &ph)); SNS_TRY(get_vec(h, 7, &sh));
+    double bnorm, rn;
+    SNS_TRY(norm2(h, b, &bnorm));
+    SNS_TRY(op_residual(h, x, b, r));
+    SNS_TRY(norm2(h, r, &rn));
+    const double tol = std::max(o.ksp_rtol * bnorm, o.ksp_atol);
+    if (o.monitor) std::printf("  0 KSP Residual norm %.12e\n", rn);
+    int its = 0, reason = 0;
+    if (!(rn == rn)) reason = SNS_KSP_DIVERGED_NANORINF;
+    else if (rn <= tol) reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL;
+    if (!reason) {
+        HIP_TRY(hipMemcpyAsync(rhat, r, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(v, 0, nd * sizeof(double), h->stream));
+        double rho = 1.0, alpha = 1.0, omega = 1.0;
+        double rho_new = rn * rn;                         // rhat.r with rhat = r
+        for (its = 1; its <= o.ksp_max_it; ++its) {
+            if (rho_new == 0.0) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+            const double beta = (rho_new / rho) * (alpha / omega);
+            hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, beta, omega, v, p);
+            SNS_TRY(pc_apply(h, p, ph));
+            SNS_TRY(halo_exchange(h, ph));
+            {   // v = A ph, fused rhat.v
+                const int32_t rows = h->n_owned;
+                const int gs = (rows + 31) / 32;
+                hipLaunchKernelGGL((k_spmv<SPMV_AX_DOT>), dim3(gs), dim3(256), 0, h->stream, rows, h->levels[0].rowptr,
+                                   h->levels[0].colind, h->levels[0].vals, ph, v, nullptr, nullptr, 0.0, rhat,
+                                   h->partial);
+                h->tm.spmv_calls++;
+                SNS_TRY(reduce_to(h, gs, 1, h->d_scal));
+            }
+            double rv;
+            SNS_TRY(fetch(h, h->d_scal, 1, &rv));
+            alpha = rho_new / rv;
+            hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, alpha, v, s, h->partial);
+            SNS_TRY(pc_apply(h, s, sh));
+            SNS_TRY(op_apply(h, sh, t));
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, s, t, h->partial);
+            SNS_TRY(reduce_to(h, g, 2, h->d_scal));
+            double ts[2];
+            SNS_TRY(fetch(h, h->d_scal, 2, ts));
+            omega = (ts[1] > 0.0) ? ts[0] / ts[1] : 0.0;
+            hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, alpha, ph, omega, sh, s, t, rhat, x,
+                               r, h->partial);
+            SNS_TRY(reduce_to(h, g, 2, h->d_scal));
+            double rr[2];
+            SNS_TRY(fetch(h, h->d_scal, 2, rr));
+            rho = rho_new;
+            rho_new = rr[0];
+            rn = std::sqrt(rr[1]);
+            if (o.monitor) std::printf("%3d KSP Residual norm %.12e\n", its, rn);
+            if (!(rn == rn) || std::isinf(rn)) { reason = SNS_KSP_DIVERGED_NANORINF; break; }
+            if (rn <= tol) { reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL; break; }
+            if (omega == 0.0) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+        }
+        if (!reason) { reason = SNS_KSP_DIVERGED_ITS; its = o.ksp_max_it; }
+    }
+    *its_out = its;
+    *reason_out = reason;
+    *rnorm_out = rn;
+    return SNS_OK;
+}
+
+// ---- FGMRES(m), right preconditioning, classical Gram-Schmidt with one re-orthogonalisation ----
+int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
+    const sns_options& o = h->opt;
+    const int m = std::min(200, std::max(1, o.gmres_restart));
+    const int64_t nd = nred_of(h), ld = ld_of(h);
+    const int g = vec_grid(nd);
+    if (h->gm_m != m) {
+        if (h->gm_V) { (void)hipFree(h->gm_V); (void)hipFree(h->gm_Z); (void)hipFree(h->d_h); }
+        SNS_TRY(dev_alloc(&h->gm_V, (size_t)(m + 1) * ld));
+        SNS_TRY(dev_alloc(&h->gm_Z, (size_t)m * ld));
+        SNS_TRY(dev_alloc(&h->d_h, (size_t)3 * (m + 8)));
+        HIP_TRY(hipMemset(h->gm_V, 0, (size_t)(m + 1) * ld * sizeof(double)));
+        HIP_TRY(hipMemset(h->gm_Z, 0, (size_t)m * ld * sizeof(double)));
+        h->gm_m = m;
+    }
+    double* V = h->gm_V;
+    double* Z = h->gm_Z;
+    double* dh1 = h->d_h;                 // pass-1 coefficients [m+8]
+    double* dh2 = h->d_h + (m + 8);       // pass-2 coefficients, then ||w||^2 at [m+8 - 1 .. ]
+    double* dnrm = h->d_h + 2 * (m + 8);
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1), y(m), hcol(2 * (m + 8) + 1);
+    double bnorm, rn;
+    SNS_TRY(norm2(h, b, &bnorm));
+    const double tol = std::max(o.ksp_rtol * bnorm, o.ksp_atol);
+    int its = 0, reason = 0;
+    double* r = V;                         // V[0] doubles as the residual vector
+    SNS_TRY(op_residual(h, x, b, r));
+    SNS_TRY(norm2(h, r, &rn));
+    if (o.monitor) std::printf("  0 KSP Residual norm %.12e\n", rn);
+    while (!reason) {
+        if (!(rn == rn) || std::isinf(rn)) { reason = SNS_KSP_DIVERGED_NANORINF; break; }
+        if (rn <= tol) { reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL; break; }
+        if (its >= o.ksp_max_it) { reason = SNS_KSP_DIVERGED_ITS; break; }
+        hipLaunchKernelGGL(k_scale_copy, dim3(g), dim3(256), 0, h->stream, nd, 1.0 / rn, r, V);
+        std::fill(gv.begin(), gv.end(), 0.0);
+        gv[0] = rn;
+        int j = 0;
+        double res = rn;
+        for (; j < m && its < o.ksp_max_it; ++j) {
+            double* vj = V + (size_t)j * ld;
+            double* zj = Z + (size_t)j * ld;
+            double* w = V + (size_t)(j + 1) * ld;
+            SNS_TRY(pc_apply(h, vj, zj));
+            SNS_TRY(op_apply(h, zj, w));
+            const int nv = j + 1;
+            for (int pass = 0; pass < 2; ++pass) {
+                double* dh = pass == 0 ? dh1 : dh2;
+                for (int c0 = 0; c0 < nv; c0 += 8) {
+                    const int cn = std::min(8, nv - c0);
+                    hipLaunchKernelGGL(k_multi_dot8, dim3(g), dim3(256), 0, h->stream, nd, cn, V + (size_t)c0 * ld, ld,
+                                       w, h->partial);
+                    SNS_TRY(reduce_to(h, g, 8, dh + c0));
+                }
+                for (int c0 = 0; c0 < nv; c0 += 8) {
+                    const int cn = std::min(8, nv - c0);
+                    const bool lastc = (pass == 1) && (c0 + 8 >= nv);
+                    hipLaunchKernelGGL(k_multi_axpy8, dim3(g), dim3(256), 0, h->stream, nd, cn, V + (size_t)c0 * ld,
+                                       ld, dh + c0, -1.0, w, lastc ? h->partial : (double*)nullptr);
+                    if (lastc) SNS_TRY(reduce_to(h, g, 1, dnrm));
+                }
+            }
+            // one device->host transfer per iteration: h1[0..nv), h2[0..nv), ||w||^2
+            SNS_TRY(fetch(h, h->d_h, 2 * (m + 8) + 1, hcol.data()));
+            double* Hj = &H[(size_t)j * (m + 1)];             // column j
+            for (int k = 0; k < nv; ++k) Hj[k] = hcol[k] + hcol[(m + 8) + k];
+            const double wn = std::sqrt(std::max(0.0, hcol[2 * (m + 8)]));
+            Hj[nv] = wn;
+            if (wn > 0.0) hipLaunchKernelGGL(k_scale_copy, dim3(g), dim3(256), 0, h->stream, nd, 1.0 / wn, w, w);
+            for (int k = 0; k < j; ++k) {                      // previous rotations
+                const double t0 = cs[k] * Hj[k] + sn[k] * Hj[k + 1];
+                Hj[k + 1] = -sn[k] * Hj[k] + cs[k] * Hj[k + 1];
+                Hj[k] = t0;
+            }
+            const double den = std::hypot(Hj[j], Hj[j + 1]);
+            cs[j] = den > 0 ? Hj[j] / den : 1.0;
+            sn[j] = den > 0 ? Hj[j + 1] / den : 0.0;
+            Hj[j] = den;
+            Hj[j + 1] = 0.0;
+            gv[j + 1] = -sn[j] * gv[j];
+            gv[j] = cs[j] * gv[j];
+            res = std::fabs(gv[j + 1]);
+            ++its;
+            if (o.monitor) std::printf("%3d KSP Residual norm %.12e\n", its, res);
+            if (res <= tol || wn == 0.0 || !(res == res)) { ++j; break; }
+        }
+        // y = H^-1 g ; x += Z y
+        for (int k = j - 1; k >= 0; --k) {
+            double sacc = gv[k];
+            for (int q = k + 1; q < j; ++q) sacc -= H[(size_t)q * (m + 1) + k] * y[q];
+            y[k] = sacc / H[(size_t)k * (m + 1) + k];
+        }
+        HIP_TRY(hipMemcpyAsync(dh1, y.data(), j * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));             // y is a stack-lifetime host buffer
+        for (int c0 = 0; c0 < j; c0 += 8) {
+            const int cn = std::min(8, j - c0);
+            hipLaunchKernelGGL(k_multi_axpy8, dim3(g), dim3(256), 0, h->stream, nd, cn, Z + (size_t)c0 * ld, ld,
+                               dh1 + c0, 1.0, x, (double*)nullptr);
+        }
+        SNS_TRY(op_residual(h, x, b, r));
+        SNS_TRY(norm2(h, r, &rn));
+    }
+    *its_out = its;
+    *reason_out = reason;
+    *rnorm_out = rn;
+    return SNS_OK;
+}
+
+int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double* rnorm) {
+    if (!h->has_matrix) { set_error("krylov_solve before a matrix was assembled"); return SNS_E_STATE; }
+    if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    int rc;
+    if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
+    else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
+    else { set_error("bad ksp_type"); return SNS_E_ARG; }
+    SNS_TRY(rc);
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->tm.krylov_ms += ms;
+    h->tm.ksp_its += *its;
+    HIP_TRY(hipGetLastError());
+    return SNS_OK;
+}
+
+int timed_assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    SNS_TRY(assemble(h, form, w, F, want_matrix));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->tm.assemble_ms += ms;
+    return SNS_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+void sns_default_options(sns_options* o) {
+    o->reynolds = 1.0;
+    o->ksp_type = SNS_KSP_FGMRES;
+    o->pc_type = SNS_PC_AMG;
+    o->ksp_rtol = 1e-8;
+    o->ksp_atol = 1e-50;
+    o->ksp_max_it = 10000;
+    o->gmres_restart = 30;
+    o->snes_rtol = 1e-8;
+    o->snes_atol = 1e-8;
+    o->snes_stol = 1e-8;
+    o->snes_max_it = 30;
+    o->amg_max_levels = 12;
+    o->amg_coarse_size = 32;
+    o->amg_agg_size = 8;
+    o->amg_nu = 2;
+    o->amg_omega = 0.8;
+    o->monitor = 0;
+    o->corrected_convection = 0;
+}
+
+const char* sns_last_error(void) { return g_err.c_str(); }
+const char* sns_version(void) { return "sns 0.1 (gfx950)"; }
+
+int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* points, const int32_t* tets,
+               const uint8_t* bc_mask, const double* bc_val, int device, const sns_options* opt) {
+    if (!out || n_nodes <= 0 || n_tets < 0 || !points || !tets || !bc_mask || !bc_val) {
+        set_error("sns_create: null or empty input");
+        return SNS_E_ARG;
+    }
+    *out = nullptr;
+    // host validation: vertex ids in range, non-degenerate tets (kernels divide by det J)
+    for (int64_t t = 0; t < n_tets; ++t) {
+        const int32_t* v = tets + 4 * t;
+        for (int a = 0; a < 4; ++a)
+            if (v[a] < 0 || v[a] >= n_nodes) { set_error("tet vertex id out of range"); return SNS_E_MESH; }
+        const double* x0 = points + 3 * (int64_t)v[0];
+        double J[3][3];
+        for (int c = 0; c < 3; ++c)
+            for (int i = 0; i < 3; ++i) J[i][c] = points[3 * (int64_t)v[c + 1] + i] - x0[i];
+        const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) -
+                           J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                           J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        if (!(std::fabs(det) > 0.0)) { set_error("degenerate tet " + std::to_string(t)); return SNS_E_MESH; }
+    }
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<sns_ctx> h(new sns_ctx);
+    if (opt) h->opt = *opt; else sns_default_options(&h->opt);
+    h->device = device;
+    h->n = n_nodes;
+    h->n_owned = n_nodes;
+    h->E = n_tets;
+    HostPattern P;
+    HostAssemblyMaps M;
+    try {
+        build_pattern(n_nodes, n_tets, tets, P, M);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return SNS_E_MESH;
+    }
+    SNS_TRY(dev_alloc(&h->tets, (size_t)4 * n_tets));
+    HIP_TRY(hipMemcpy(h->tets, tets, (size_t)4 * n_tets * sizeof(int32_t), hipMemcpyHostToDevice));
+    SNS_TRY(dev_alloc(&h->pts, (size_t)3 * n_nodes));
+    HIP_TRY(hipMemcpy(h->pts, points, (size_t)3 * n_nodes * sizeof(double), hipMemcpyHostToDevice));
+    SNS_TRY(dev_alloc(&h->bc_mask, (size_t)4 * n_nodes));
+    HIP_TRY(hipMemcpy(h->bc_mask, bc_mask, (size_t)4 * n_nodes, hipMemcpyHostToDevice));
+    SNS_TRY(dev_alloc(&h->bc_val, (size_t)4 * n_nodes));
+    HIP_TRY(hipMemcpy(h->bc_val, bc_val, (size_t)4 * n_nodes * sizeof(double), hipMemcpyHostToDevice));
+    SNS_TRY(dev_upload(&h->nt_ptr, M.nt_ptr, nullptr));
+    SNS_TRY(dev_upload(&h->nt_idx, M.nt_idx, nullptr));
+    SNS_TRY(dev_upload(&h->c_ptr, M.c_ptr, nullptr));
+    SNS_TRY(dev_upload(&h->c_idx, M.c_idx, nullptr));
+    h->levels.emplace_back();
+    h->slot_row.push_back(nullptr);
+    h->empty_c.push_back(nullptr);
+    h->pong.push_back(nullptr);
+    SNS_TRY(upload_pattern(h->levels[0], P, &h->slot_row[0], nullptr));
+    h->levels[0].n_owned = n_nodes;
+    SNS_TRY(alloc_level_vectors(h->levels[0]));
+    SNS_TRY(dev_alloc(&h->pong[0], 4 * (size_t)n_nodes));
+    HIP_TRY(hipMemset(h->pong[0], 0, 4 * (size_t)n_nodes * sizeof(double)));
+    {   // free mask of level 0 = !bc
+        std::vector<uint8_t> fm((size_t)4 * n_nodes);
+        for (size_t i = 0; i < fm.size(); ++i) fm[i] = bc_mask[i] ? 0 : 1;
+        SNS_TRY(dev_upload(&h->levels[0].free_mask, fm, nullptr));
+    }
+    SNS_TRY(dev_alloc(&h->partial, (size_t)65536 * 8));
+    SNS_TRY(dev_alloc(&h->d_scal, 256));
+    SNS_TRY(dev_alloc(&h->d_sing, 1));
+    HIP_TRY(hipMemset(h->d_sing, 0, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&h->h_scal, 1024 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    // the hierarchy is built lazily (first pc_setup) so that sns_attach_comm can shrink n_owned first
+    HIP_TRY(hipDeviceSynchronize());
+    h->tm = sns_timings{};
+    h->pattern.reset(new HostPattern(std::move(P)));
+    *out = h.release();
+    return SNS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int ensure_hierarchy(sns_ctx* h) {
+    if (!h->pattern) return SNS_OK;                       // already built
+    if (h->opt.pc_type != SNS_PC_AMG) return SNS_OK;      // built when (if) AMG is first asked for
+    int rc = build_hierarchy(h, *h->pattern);
+    h->pattern.reset();
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int sns_destroy(sns_handle h) {
+    if (!h) return SNS_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(h->tets); fr(h->pts); fr(h->bc_mask); fr(h->bc_val);
+    fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->Ke); fr(h->Fe);
+    for (auto& L : h->levels) {
+        fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
+        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv);
+    }
+    for (auto p : h->slot_row) fr(p);
+    for (auto p : h->empty_c) fr(p);
+    for (auto p : h->pong) fr(p);
+    for (auto p : h->kv) fr(p);
+    fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
+    fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
+    if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->comm) {
+        fr(h->comm->send_idx); fr(h->comm->recv_idx); fr(h->comm->send_buf); fr(h->comm->recv_buf);
+        if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
+    }
+    delete h;
+    return SNS_OK;
+}
+
+int sns_set_stream(sns_handle h, void* s) {
+    if (!h) return SNS_E_ARG;
+    h->stream = (hipStream_t)s;
+    return SNS_OK;
+}
+int sns_set_options(sns_handle h, const sns_options* o) {
+    if (!h || !o) return SNS_E_ARG;
+    const bool pc_changed = (o->pc_type != h->opt.pc_type);
+    h->opt = *o;
+    if (pc_changed) h->pc_ready = false;
+    return SNS_OK;
+}
+int sns_get_options(sns_handle h, sns_options* o) {
+    if (!h || !o) return SNS_E_ARG;
+    *o = h->opt;
+    return SNS_OK;
+}
+int sns_get_sizes(sns_handle h, int32_t* nl, int32_t* no, int64_t* nt, int64_t* nnzb) {
+    if (!h) return SNS_E_ARG;
+    if (nl) *nl = h->n;
+    if (no) *no = h->n_owned;
+    if (nt) *nt = h->E;
+    if (nnzb) *nnzb = h->levels[0].nnzb;
+    return SNS_OK;
+}
+
+int sns_comm_unique_id(char id_out[128]) {
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, 128);
+    return SNS_OK;
+}
+
+int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int32_t n_owned, int n_nbr,
+                    const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
+                    const int32_t* recv_idx) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks || n_owned < 0 || n_owned > h->n) {
+        set_error("sns_attach_comm: bad arguments");
+        return SNS_E_ARG;
+    }
+    if (h->has_matrix || !h->pattern) {
+        set_error("sns_attach_comm must directly follow sns_create");
+        return SNS_E_STATE;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    h->comm.reset(new Comm);
+    Comm& c = *h->comm;
+    c.rank = rank;
+    c.nranks = nranks;
+    ncclUniqueId id;
+    std::memcpy(&id, uid, 128);
+    NCCL_TRY(ncclCommInitRank(&c.comm, nranks, id, rank));
+    h->n_owned = n_owned;
+    h->levels[0].n_owned = n_owned;
+    c.nbr.assign(nbr, nbr + n_nbr);
+    c.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+    c.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+    const int32_t ns = c.send_ptr[n_nbr], nr = c.recv_ptr[n_nbr];
+    for (int32_t i = 0; i < ns; ++i)
+        if (send_idx[i] < 0 || send_idx[i] >= n_owned) { set_error("send_idx outside owned range"); return SNS_E_ARG; }
+    for (int32_t i = 0; i < nr; ++i)
+        if (recv_idx[i] < n_owned || recv_idx[i] >= h->n) { set_error("recv_idx outside ghost range"); return SNS_E_ARG; }
+    std::vector<int32_t> si(send_idx, send_idx + ns), ri(recv_idx, recv_idx + nr);
+    SNS_TRY(dev_upload(&c.send_idx, si, nullptr));
+    SNS_TRY(dev_upload(&c.recv_idx, ri, nullptr));
+    SNS_TRY(dev_alloc(&c.send_buf, 4 * (size_t)ns));
+    SNS_TRY(dev_alloc(&c.recv_buf, 4 * (size_t)nr));
+    // ghost dofs never take part in the per-rank preconditioner's transfer operators
+    {
+        std::vector<uint8_t> fm((size_t)4 * h->n);
+        HIP_TRY(hipMemcpy(fm.data(), h->levels[0].free_mask, fm.size(), hipMemcpyDeviceToHost));
+        for (size_t i = (size_t)4 * n_owned; i < fm.size(); ++i) fm[i] = 0;
+        HIP_TRY(hipMemcpy(h->levels[0].free_mask, fm.data(), fm.size(), hipMemcpyHostToDevice));
+    }
+    return SNS_OK;
+}
+
+int sns_residual(sns_handle h, int form, const double* w, double* F) {
+    if (!h || !F) return SNS_E_ARG;
+    return timed_assemble(h, form, w, F, false);
+}
+int sns_jacobian(sns_handle h, int form, const double* w, double* F) {
+    if (!h) return SNS_E_ARG;
+    return timed_assemble(h, form, w, F, true);
+}
+int sns_spmv(sns_handle h, const double* x, double* y) {
+    if (!h || !x || !y) return SNS_E_ARG;
+    if (!h->has_matrix) { set_error("spmv before a matrix was assembled"); return SNS_E_STATE; }
+    SNS_TRY(op_apply(h, const_cast<double*>(x), y));
+    return sync_stream(h);
+}
+int sns_pc_setup(sns_handle h) {
+    if (!h) return SNS_E_ARG;
+    SNS_TRY(ensure_hierarchy(h));
+    return pc_setup(h);
+}
+int sns_pc_apply(sns_handle h, const double* r, double* z) {
+    if (!h || !r || !z) return SNS_E_ARG;
+    if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) { set_error("pc_apply before pc_setup"); return SNS_E_STATE; }
+    SNS_TRY(pc_apply(h, r, z));
+    return sync_stream(h);
+}
+int sns_krylov_solve(sns_handle h, const double* b, double* x, int* its, int* reason, double* rnorm) {
+    if (!h || !b || !x || !its || !reason || !rnorm) return SNS_E_ARG;
+    SNS_TRY(ensure_hierarchy(h));
+    return krylov(h, b, x, its, reason, rnorm);
+}
+
+int sns_stokes_solve(sns_handle h, double* U, int* ksp_its, int* reason, double* rnorm) {
+    if (!h || !U || !ksp_its || !reason || !rnorm) return SNS_E_ARG;
+    SNS_TRY(ensure_hierarchy(h));
+    const int64_t nd = nred_of(h), ld = ld_of(h);
+    if (!h->nw_F) {
+        SNS_TRY(dev_alloc(&h->nw_F, (size_t)ld)); SNS_TRY(dev_alloc(&h->nw_y, (size_t)ld));
+        SNS_TRY(dev_alloc(&h->nw_w, (size_t)ld)); SNS_TRY(dev_alloc(&h->nw_t, (size_t)ld));
+        HIP_TRY(hipMemset(h->nw_F, 0, ld * sizeof(double))); HIP_TRY(hipMemset(h->nw_y, 0, ld * sizeof(double)));
+        HIP_TRY(hipMemset(h->nw_w, 0, ld * sizeof(double))); HIP_TRY(hipMemset(h->nw_t, 0, ld * sizeof(double)));
+    }
+    // one Newton step of the linear problem from w = 0:  A U = -F(0),  F(0) = lifting, F_B = -g   (:198-214)
+    SNS_TRY(timed_assemble(h, SNS_FORM_STOKES, nullptr, h->nw_F, true));
+    hipLaunchKernelGGL(k_scale_copy, dim3(vec_grid(nd)), dim3(256), 0, h->stream, nd, -1.0, h->nw_F, h->nw_F);
+    HIP_TRY(hipMemsetAsync(U, 0, nd * sizeof(double), h->stream));
+    return krylov(h, h->nw_F, U, ksp_its, reason, rnorm);
+}
+
+int sns_newton_solve(sns_handle h, double* w, int* its_out, int* reason_out, int* total_ksp, double* hist,
+                     int hist_cap) {
+    if (!h || !w || !its_out || !reason_out) return SNS_E_ARG;
+    SNS_TRY(ensure_hierarchy(h));
+    const sns_options& o = h->opt;
+    const int64_t nd = nred_of(h), ld = ld_of(h);
+    const int g = vec_grid(nd);
+    if (!h->nw_F) {
+        SNS_TRY(dev_alloc(&h->nw_F, (size_t)ld)); SNS_TRY(dev_alloc(&h->nw_y, (size_t)ld));
+        SNS_TRY(dev_alloc(&h->nw_w, (size_t)ld)); SNS_TRY(dev_alloc(&h->nw_t, (size_t)ld));
+        HIP_TRY(hipMemset(h->nw_F, 0, ld * sizeof(double))); HIP_TRY(hipMemset(h->nw_y, 0, ld * sizeof(double)));
+        HIP_TRY(hipMemset(h->nw_w, 0, ld * sizeof(double))); HIP_TRY(hipMemset(h->nw_t, 0, ld * sizeof(double)));
+    }
+    double *F = h->nw_F, *y = h->nw_y, *wn = h->nw_w, *Fn = h->nw_t;
+    int ksp_total = 0, nh = 0;
+    auto record = [&](double f) { if (hist && nh < hist_cap) hist[nh] = f; ++nh; };
+    SNS_TRY(halo_exchange(h, w));
+    SNS_TRY(timed_assemble(h, SNS_FORM_NS, w, F, true));
+    double f, f0;
+    SNS_TRY(norm2(h, F, &f));
+    f0 = f;
+    record(f);
+    if (o.monitor) std::printf("  0 SNES Function norm %.12e\n", f);
+    int reason = 0, it = 0;
+    if (!(f == f)) reason = SNS_SNES_DIVERGED_FNORM_NAN;
+    else if (f < o.snes_atol) reason = SNS_SNES_CONVERGED_FNORM_ABS;
+    while (!reason) {
+        if (it >= o.snes_max_it) { reason = SNS_SNES_DIVERGED_MAX_IT; break; }
+        ++it;
+        // J y = F
+        HIP_TRY(hipMemsetAsync(y, 0, nd * sizeof(double), h->stream));
+        int kits = 0, kreason = 0;
+        double krn = 0;
+        SNS_TRY(krylov(h, F, y, &kits, &kreason, &krn));
+        ksp_total += kits;
+        if (kreason < 0) { reason = SNS_SNES_DIVERGED_LINEAR_SOLVE; break; }
+        // bt line search (cubic backtracking, alpha 1e-4), x_new = x - lambda y
+        double initslope;
+        {
+            double* Jy = Fn;                                 // borrow
+            SNS_TRY(op_apply(h, y, Jy));
+            SNS_TRY(dot(h, F, Jy, &initslope));
+        }
+        if (initslope > 0) initslope = -initslope;
+        if (initslope == 0) initslope = -1.0;
+        double ynorm;
+        SNS_TRY(norm2(h, y, &ynorm));
+        const double ls_alpha = 1e-4;
+        double lam = 1.0, gn = 0.0;
+        auto trial = [&](double l) -> int {
+            HIP_TRY(hipMemcpyAsync(wn, w, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, h->stream, nd, -l, y, 1.0, wn);
+            SNS_TRY(halo_exchange(h, wn));
+            SNS_TRY(timed_assemble(h, SNS_FORM_NS, wn, Fn, false));
+            return norm2(h, Fn, &gn);
+        };
+        SNS_TRY(trial(lam));
+        bool ok = 0.5 * gn * gn <= 0.5 * f * f + lam * ls_alpha * initslope;
+        if (!ok && gn == gn) {
+            double lamprev = lam, gprev = gn;
+            double lamtemp = -initslope / (gn * gn - f * f - 2.0 * lam * initslope);
+            lam = std::min(std::max(lamtemp, 0.1 * lam), 0.5 * lam);
+            for (int k = 0; k < 40; ++k) {
+                SNS_TRY(trial(lam));
+                if (0.5 * gn * gn <= 0.5 * f * f + lam * ls_alpha * initslope) { ok = true; break; }
+                const double t1 = 0.5 * (gn * gn - f * f) - lam * initslope;
+                const double t2 = 0.5 * (gprev * gprev - f * f) - lamprev * initslope;
+                const double a = (t1 / (lam * lam) - t2 / (lamprev * lamprev)) / (lam - lamprev);
+                const double bq = (-lamprev * t1 / (lam * lam) + lam * t2 / (lamprev * lamprev)) / (lam - lamprev);
+                const double d = std::max(bq * bq - 3 * a * initslope, 0.0);
+                lamtemp = (a == 0) ? -initslope / (2.0 * bq) : (-bq + std::sqrt(d)) / (3.0 * a);
+                lamprev = lam;
+                gprev = gn;
+                lam = std::min(std::max(lamtemp, 0.1 * lam), 0.5 * lam);
+            }
+        }
+        if (!ok) { reason = (gn == gn) ? SNS_SNES_DIVERGED_LINE_SEARCH : SNS_SNES_DIVERGED_FNORM_NAN; break; }
+        HIP_TRY(hipMemcpyAsync(w, wn, ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        double xnorm;
+        SNS_TRY(norm2(h, w, &xnorm));
+        f = gn;
+        record(f);
+        if (o.monitor) std::printf("%3d SNES Function norm %.12e  (ksp its %d, lambda %.3g)\n", it, f, kits, lam);
+        if (f < o.snes_atol) reason = SNS_SNES_CONVERGED_FNORM_ABS;
+        else if (f <= o.snes_rtol * f0) reason = SNS_SNES_CONVERGED_FNORM_RELATIVE;
+        else if (lam * ynorm < o.snes_stol * xnorm) reason = SNS_SNES_CONVERGED_SNORM_RELATIVE;
+        if (reason) break;
+        SNS_TRY(timed_assemble(h, SNS_FORM_NS, w, F, true));
+    }
+    *its_out = it;
+    *reason_out = reason;
+    if (total_ksp) *total_ksp = ksp_total;
+    return SNS_OK;
+}
+
+int sns_get_bsr(sns_handle h, int32_t* n_rows, int64_t* nnzb, const int32_t** rowptr, const int32_t** colind,
+                const double** vals) {
+    if (!h) return SNS_E_ARG;
+    const Level& L = h->levels[0];
+    if (n_rows) *n_rows = L.n;
+    if (nnzb) *nnzb = L.nnzb;
+    if (rowptr) *rowptr = L.rowptr;
+    if (colind) *colind = L.colind;
+    if (vals) *vals = L.vals;
+    return SNS_OK;
+}
+int sns_get_element_scratch(sns_handle h, const double** Ke, const double** Fe) {
+    if (!h) return SNS_E_ARG;
+    if (Ke) *Ke = h->Ke;
+    if (Fe) *Fe = h->Fe;
+    return SNS_OK;
+}
+int sns_export(sns_handle h, int what, void* dst, int64_t nbytes) {
+    if (!h || !dst) return SNS_E_ARG;
+    const Level& L = h->levels[0];
+    const void* src = nullptr;
+    int64_t need = 0;
+    switch (what) {
+        case SNS_EXPORT_ROWPTR: src = L.rowptr; need = ((int64_t)L.n + 1) * 4; break;
+        case SNS_EXPORT_COLIND: src = L.colind; need = L.nnzb * 4; break;
+        case SNS_EXPORT_VALS: src = L.vals; need = L.nnzb * 16 * 8; break;
+        case SNS_EXPORT_KE: src = h->Ke; need = h->E * 256 * 8; break;
+        case SNS_EXPORT_FE: src = h->Fe; need = h->E * 16 * 8; break;
+        default: set_error("sns_export: unknown array"); return SNS_E_ARG;
+    }
+    if (!src) { set_error("sns_export: array not produced yet"); return SNS_E_STATE; }
+    if (need != nbytes) { set_error("sns_export: size mismatch, need " + std::to_string(need)); return SNS_E_ARG; }
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)need, hipMemcpyDeviceToDevice, h->stream));
+    return sync_stream(h);
+}
+int sns_get_timings(sns_handle h, sns_timings* t) {
+    if (!h || !t) return SNS_E_ARG;
+    *t = h->tm;
+    t->amg_levels = (int)h->levels.size();
+    return SNS_OK;
+}
+int sns_reset_timings(sns_handle h) {
+    if (!h) return SNS_E_ARG;
+    h->tm = sns_timings{};
+    return SNS_OK;
+}
+
+int sns_bench_spmv(sns_handle h, const double* x, double* y, int reps, double* ms_avg) {
+    if (!h || !x || !y || reps <= 0 || !ms_avg) return SNS_E_ARG;
+    if (!h->has_matrix) { set_error("bench_spmv before a matrix was assembled"); return SNS_E_STATE; }
+    launch_spmv<SPMV_AX>(h, h->levels[0], h->n_owned, x, y, nullptr, 0.0, nullptr);   // warm
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) launch_spmv<SPMV_AX>(h, h->levels[0], h->n_owned, x, y, nullptr, 0.0, nullptr);
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_avg = ms / reps;
+    HIP_TRY(hipGetLastError());
+    return SNS_OK;
+}
+int sns_bench_assemble(sns_handle h, int form, const double* w, double* F, int reps, double* ms_avg) {
+    if (!h || reps <= 0 || !ms_avg) return SNS_E_ARG;
+    SNS_TRY(assemble(h, form, w, F, true));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) SNS_TRY(assemble(h, form, w, F, true));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_avg = ms / reps;
+    return SNS_OK;
+}
+
+}  // extern "C"

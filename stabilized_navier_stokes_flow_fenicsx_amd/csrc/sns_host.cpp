@@ -1,0 +1,223 @@
+// Host-side symbolic setup: BSR sparsity pattern from the tet connectivity,
+// gather maps for the atomic-free assembly, and the aggregation hierarchy.
+//
+// Replaces what DOLFINx does behind `create_matrix(problem.a)`
+// (NavierStokesChannelFlow.py:272: sparsity pattern from the dofmap) and what
+// PETSc's MatSetValuesLocal row search does on every assembly (:74): here the
+// (tet, a, b) -> block-slot relation is resolved ONCE and inverted, so the
+// device never searches and never needs atomics.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+#include "sns_internal.h"
+
+namespace sns {
+
+void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, HostAssemblyMaps& M) {
+    if (E * 16 > (int64_t)INT32_MAX) throw std::runtime_error("mesh too large for int32 element-block ids");
+    // ---- node -> incident (tet, a) ------------------------------------------
+    M.nt_ptr.assign((size_t)n + 1, 0);
+    for (int64_t t = 0; t < E; ++t)
+        for (int a = 0; a < 4; ++a) {
+            int32_t v = tets[4 * t + a];
+            if (v < 0 || v >= n) throw std::runtime_error("tet vertex id out of range");
+            M.nt_ptr[(size_t)v + 1]++;
+        }
+    for (int32_t i = 0; i < n; ++i) M.nt_ptr[i + 1] += M.nt_ptr[i];
+    M.nt_idx.resize((size_t)4 * E);
+    {
+        std::vector<int64_t> cur(M.nt_ptr.begin(), M.nt_ptr.end() - 1);
+        for (int64_t t = 0; t < E; ++t)                       // tet order => deterministic gather order
+            for (int a = 0; a < 4; ++a) M.nt_idx[(size_t)cur[tets[4 * t + a]]++] = (int32_t)(4 * t + a);
+    }
+    // ---- rows: sorted unique neighbour nodes ----------------------------------
+    P.n = n;
+    P.rowptr.assign((size_t)n + 1, 0);
+    std::vector<int32_t> cnt((size_t)n, 0);
+#pragma omp parallel
+    {
+        std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n; ++i) {
+            tmp.clear();
+            for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
+                const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
+                tmp.insert(tmp.end(), tv, tv + 4);
+            }
+            if (tmp.empty()) tmp.push_back(i);                // isolated node: keep a diagonal
+            std::sort(tmp.begin(), tmp.end());
+            cnt[i] = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+        }
+    }
+    int64_t nnzb = 0;
+    for (int32_t i = 0; i < n; ++i) nnzb += cnt[i];
+    if (nnzb > (int64_t)INT32_MAX) throw std::runtime_error("nnz blocks exceed int32 (shard the mesh)");
+    for (int32_t i = 0; i < n; ++i) P.rowptr[i + 1] = P.rowptr[i] + cnt[i];
+    P.nnzb = nnzb;
+    P.colind.resize((size_t)nnzb);
+    P.diag.resize((size_t)n);
+#pragma omp parallel
+    {
+        std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n; ++i) {
+            tmp.clear();
+            for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
+                const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
+                tmp.insert(tmp.end(), tv, tv + 4);
+            }
+            if (tmp.empty()) tmp.push_back(i);
+            std::sort(tmp.begin(), tmp.end());
+            auto e = std::unique(tmp.begin(), tmp.end());
+            std::copy(tmp.begin(), e, P.colind.begin() + P.rowptr[i]);
+            P.diag[i] = P.rowptr[i] + (int32_t)(std::lower_bound(tmp.begin(), e, i) - tmp.begin());
+        }
+    }
+    // ---- slot -> contributing element blocks -----------------------------------
+    // Row i receives block (a,b) of every incident (tet,a); count per slot, then fill in
+    // (incident-tet order, b order): rows are independent, so this is parallel AND deterministic.
+    M.c_ptr.assign((size_t)nnzb + 1, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t* cb = P.colind.data() + P.rowptr[i];
+        const int32_t len = P.rowptr[i + 1] - P.rowptr[i];
+        for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
+            const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
+            for (int b = 0; b < 4; ++b) {
+                int32_t s = P.rowptr[i] + (int32_t)(std::lower_bound(cb, cb + len, tv[b]) - cb);
+                M.c_ptr[(size_t)s + 1]++;
+            }
+        }
+    }
+    for (int64_t s = 0; s < nnzb; ++s) M.c_ptr[s + 1] += M.c_ptr[s];
+    M.c_idx.resize((size_t)16 * E);
+#pragma omp parallel
+    {
+        std::vector<int32_t> fill;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t* cb = P.colind.data() + P.rowptr[i];
+            const int32_t len = P.rowptr[i + 1] - P.rowptr[i];
+            fill.assign((size_t)len, 0);
+            for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
+                const int32_t ta = M.nt_idx[k];
+                const int32_t* tv = tets + 4 * (int64_t)(ta >> 2);
+                for (int b = 0; b < 4; ++b) {
+                    int32_t j = (int32_t)(std::lower_bound(cb, cb + len, tv[b]) - cb);
+                    int64_t s = P.rowptr[i] + j;
+                    M.c_idx[(size_t)(M.c_ptr[s] + fill[j]++)] = (ta >> 2) * 16 + (ta & 3) * 4 + b;
+                }
+            }
+        }
+    }
+}
+
+// Greedy size-limited aggregation on the node graph (plain aggregation AMG).
+// A seed takes up to max_agg-1 still-free neighbours; a free node with no free
+// neighbour joins the aggregate of its first aggregated neighbour.  Sequential
+// and therefore deterministic; O(nnzb).  Rows >= fine.n_owned ... are handled by
+// the caller through `owned` (nodes outside are never aggregated).
+static void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
+                            int32_t& nc) {
+    agg.assign((size_t)F.n, -1);
+    nc = 0;
+    for (int32_t i = 0; i < n_active; ++i) {
+        if (agg[i] >= 0) continue;
+        int taken = 0;
+        int32_t first_agg_nb = -1;
+        for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+            int32_t j = F.colind[k];
+            if (j == i || j >= n_active) continue;
+            if (agg[j] < 0) {
+                if (taken < max_agg - 1) { agg[j] = nc; ++taken; }
+            } else if (first_agg_nb < 0) first_agg_nb = agg[j];
+        }
+        if (taken == 0 && first_agg_nb >= 0) { agg[i] = first_agg_nb; continue; }
+        agg[i] = nc++;
+    }
+}
+
+void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_agg, HostAggregation& A) {
+    aggregate_nodes(F, n_active, max_agg, A.agg, A.nc);
+    const int32_t nc = A.nc;
+    // members
+    A.m_ptr.assign((size_t)nc + 1, 0);
+    for (int32_t i = 0; i < n_active; ++i) A.m_ptr[A.agg[i] + 1]++;
+    for (int32_t I = 0; I < nc; ++I) A.m_ptr[I + 1] += A.m_ptr[I];
+    A.m_idx.resize((size_t)n_active);
+    {
+        std::vector<int32_t> cur(A.m_ptr.begin(), A.m_ptr.end() - 1);
+        for (int32_t i = 0; i < n_active; ++i) A.m_idx[cur[A.agg[i]]++] = i;
+    }
+    // coarse pattern + RAP gather lists: coarse slot (I,J) <- fine slots (i,j), i in I, j in J
+    HostPattern& C = A.coarse;
+    C.n = nc;
+    C.rowptr.assign((size_t)nc + 1, 0);
+    std::vector<std::vector<int32_t>> rows((size_t)nc);
+#pragma omp parallel
+    {
+        std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t I = 0; I < nc; ++I) {
+            tmp.clear();
+            for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
+                int32_t i = A.m_idx[m];
+                for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                    int32_t j = F.colind[k];
+                    if (j < n_active) tmp.push_back(A.agg[j]);
+                }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            rows[I] = tmp;
+        }
+    }
+    for (int32_t I = 0; I < nc; ++I) C.rowptr[I + 1] = C.rowptr[I] + (int32_t)rows[I].size();
+    C.nnzb = C.rowptr[nc];
+    C.colind.resize((size_t)C.nnzb);
+    C.diag.resize((size_t)nc);
+    A.r_ptr.assign((size_t)C.nnzb + 1, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t I = 0; I < nc; ++I) {
+        std::copy(rows[I].begin(), rows[I].end(), C.colind.begin() + C.rowptr[I]);
+        C.diag[I] = C.rowptr[I] + (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), I) - rows[I].begin());
+        for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
+            int32_t i = A.m_idx[m];
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                int32_t j = F.colind[k];
+                if (j >= n_active) continue;
+                int32_t s = C.rowptr[I] +
+                            (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), A.agg[j]) - rows[I].begin());
+                A.r_ptr[(size_t)s + 1]++;
+            }
+        }
+    }
+    for (int64_t s = 0; s < C.nnzb; ++s) A.r_ptr[s + 1] += A.r_ptr[s];
+    A.r_idx.resize((size_t)A.r_ptr[C.nnzb]);
+#pragma omp parallel
+    {
+        std::vector<int32_t> fill;
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t I = 0; I < nc; ++I) {
+            fill.assign(rows[I].size(), 0);
+            for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
+                int32_t i = A.m_idx[m];
+                for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                    int32_t j = F.colind[k];
+                    if (j >= n_active) continue;
+                    int32_t jj = (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), A.agg[j]) - rows[I].begin());
+                    int64_t s = C.rowptr[I] + jj;
+                    A.r_idx[(size_t)(A.r_ptr[s] + fill[jj]++)] = k;
+                }
+            }
+        }
+    }
+}
+
+void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A) {
+    build_aggregation_active(fine, fine.n, max_agg, A);
+}
+
+}  // namespace sns

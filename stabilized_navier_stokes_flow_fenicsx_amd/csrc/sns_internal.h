@@ -1,0 +1,67 @@
+// Internal structures shared by the host setup code, the HIP kernels and the
+// C-ABI layer.  Not installed; the public surface is include/sns.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sns.h"
+
+namespace sns {
+
+// ---- host-side symbolic data (built once per mesh, sns_host.cpp) ------------
+struct HostPattern {
+    int32_t n = 0;                       // block rows (nodes)
+    int64_t nnzb = 0;
+    std::vector<int32_t> rowptr, colind; // BSR pattern, columns sorted per row
+    std::vector<int32_t> diag;           // slot of the diagonal block of each row
+};
+
+struct HostAssemblyMaps {
+    // node -> incident (tet*4 + a), tet order: gather list for the residual
+    std::vector<int64_t> nt_ptr;         // n+1
+    std::vector<int32_t> nt_idx;         // 4*E   (tet*4+a fits int32 up to 536M tets)
+    // BSR slot -> contributing element blocks (tet*16 + a*4 + b), fixed order
+    std::vector<int64_t> c_ptr;          // nnzb+1
+    std::vector<int32_t> c_idx;          // 16*E  (tet*16+ab fits int32 up to 134M tets)
+};
+
+struct HostAggregation {
+    int32_t nc = 0;
+    std::vector<int32_t> agg;            // fine node -> aggregate
+    std::vector<int32_t> m_ptr, m_idx;   // aggregate -> member fine nodes
+    HostPattern coarse;                  // coarse BSR pattern
+    std::vector<int64_t> r_ptr;          // coarse slot -> fine slots (RAP gather)
+    std::vector<int32_t> r_idx;
+};
+
+void build_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets, HostPattern& P,
+                   HostAssemblyMaps& M);
+void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A);
+// same, but only nodes [0, n_active) take part (distributed level 0: owned nodes only)
+void build_aggregation_active(const HostPattern& fine, int32_t n_active, int max_agg, HostAggregation& A);
+
+// ---- device-side level of the operator hierarchy ----------------------------
+struct Level {
+    int32_t n = 0;                       // local block rows (owned + ghost on level 0)
+    int32_t n_owned = 0;                 // rows that are solved for (== n when serial)
+    int64_t nnzb = 0;
+    int32_t *rowptr = nullptr, *colind = nullptr, *diag = nullptr;
+    double* vals = nullptr;              // nnzb*16, block row-major
+    double* dinv = nullptr;              // n*16
+    // to the next coarser level
+    int32_t nc = 0;
+    int32_t* agg = nullptr;              // n
+    int32_t *m_ptr = nullptr, *m_idx = nullptr;
+    int64_t* r_ptr = nullptr;
+    int32_t* r_idx = nullptr;
+    uint8_t* free_mask = nullptr;        // 4*n: 1 where dof takes part in transfer (level 0: !bc), else all 1
+    // work vectors (4*n doubles)
+    double *x = nullptr, *b = nullptr, *r = nullptr;
+    // coarsest level: dense inverse (4n x 4n), row-major
+    double* dense_inv = nullptr;
+};
+
+void set_error(const std::string& s);
+
+}  // namespace sns

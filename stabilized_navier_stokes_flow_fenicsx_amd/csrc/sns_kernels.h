@@ -1,0 +1,60 @@
+// Kernel declarations shared between sns_kernels.hip and sns_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sns.h"
+
+namespace sns {
+
+constexpr int EL_TETS_PER_BLOCK = 16;   // tets per 256-thread workgroup of k_element
+
+enum SpmvMode { SPMV_AX = 0, SPMV_B_MINUS_AX = 1, SPMV_JACOBI = 2, SPMV_AX_DOT = 3 };
+
+template <int FORM, bool corrected>
+__global__ void k_element(int64_t n_tets, const int32_t* tets, const double* pts, const double* w,
+                          const uint8_t* bc_mask, const double* bc_val, double nu, int store_K, double* Ke,
+                          double* Fe);
+__global__ void k_gather_matrix(int64_t nnzb, const int64_t* c_ptr, const int32_t* c_idx, const int32_t* slot_row,
+                                const int32_t* colind, const uint8_t* bc_mask, const double* Ke, double* vals);
+__global__ void k_gather_residual(int32_t n_rows, const int64_t* nt_ptr, const int32_t* nt_idx,
+                                  const uint8_t* bc_mask, const double* bc_val, const double* w, const double* Fe,
+                                  double* F);
+template <int MODE>
+__global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
+                       const double* x, double* y, const double* bvec, const double* dinv, double omega,
+                       const double* dotw, double* partial);
+__global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
+__global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
+__global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);
+__global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);
+__global__ void k_axpby(int64_t n, double a, const double* x, double b, double* y);
+__global__ void k_axpbypcz(int64_t n, double a, const double* x, double b, const double* y, double c, double* z);
+__global__ void k_bicg_p(int64_t n, const double* r, double beta, double omega, const double* v, double* p);
+__global__ void k_bicg_s(int64_t n, const double* r, double alpha, const double* v, double* s, double* partial);
+__global__ void k_bicg_xr(int64_t n, double alpha, const double* ph, double omega, const double* sh,
+                          const double* s, const double* t, const double* rhat, double* x, double* r,
+                          double* partial);
+__global__ void k_multi_dot8(int64_t n, int nv, const double* V, int64_t ldv, const double* w, double* partial);
+__global__ void k_multi_axpy8(int64_t n, int nv, const double* V, int64_t ldv, const double* h, double sign,
+                              double* w, double* partial);
+__global__ void k_scale_copy(int64_t n, double a, const double* x, double* y);
+__global__ void k_restrict(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
+                           const double* r, double* bc);
+__global__ void k_prolong_add(int32_t n, const int32_t* agg, const uint8_t* free_mask, const double* xc, double* x);
+__global__ void k_galerkin(int64_t nnzb_c, const int64_t* r_ptr, const int32_t* r_idx, const int32_t* slot_row_f,
+                           const int32_t* colind_f, const uint8_t* free_mask, const double* vals_f,
+                           const int32_t* slot_row_c, const int32_t* colind_c, const uint8_t* empty_c,
+                           double* vals_c);
+__global__ void k_empty_coarse(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
+                               uint8_t* empty_c);
+__global__ void k_bsr_to_dense(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals,
+                               double* D);
+__global__ void k_dense_inverse(int N, double* A, int* piv, int* singular);
+__global__ void k_dense_matvec(int N, const double* D, const double* x, double* y);
+__global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
+__global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
+__global__ void k_fill_slot_row(int32_t n, const int32_t* rowptr, int32_t* slot_row);
+
+}  // namespace sns

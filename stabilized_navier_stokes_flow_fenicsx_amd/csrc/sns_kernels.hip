@@ -1,0 +1,935 @@
+// HIP kernels for gfx950 (MI355X, CDNA4): wave64, fp64 vector ALU, LDS staging.
+// No MFMA anywhere: every kernel here is HBM-bandwidth bound or fp64-VALU bound
+// (DESIGN.md "Kernels").  All kernels are written for wave64 only.
+//
+// K1  k_element<FORM>        element Jacobian blocks + residual, LDS-staged
+//     k_gather_matrix        BSR slot <- sum of element blocks (atomic-free scatter)
+//     k_gather_residual      node    <- sum of element residuals, F_B = w_B - g
+// K2  k_spmv<MODE>           BSR4 SpMV, 8 lanes per block row, fused epilogues
+// K3  k_dinv, (Jacobi sweep = k_spmv<MODE_JACOBI>)
+// K4  vector kernels with fused dots (two-stage deterministic reductions)
+//     AMG transfer / Galerkin kernels, dense coarse inverse
+// K7  halo pack / unpack
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sns_kernels.h"
+
+namespace sns {
+
+// ============================================================================
+// K1: element kernel
+// ============================================================================
+// 16 lanes per tet: lane (a,b) owns the 4x4 block coupling local vertices a,b.
+// One wave = 4 tets, one 256-thread workgroup = 16 tets.  Nodal coordinates and
+// the nodal state are staged in LDS once per tet; lanes 0..3 of a tet compute
+// the geometry and the per-quadrature-point scalars (tau, nu_LSIC, u_q, ...)
+// into LDS, then all 16 lanes accumulate their block over the 4 points.  The
+// 256 blocks of a workgroup are transposed through LDS so that every store
+// instruction writes 1 KiB contiguous.
+//
+// Math: SURVEY.md Appendix A == oracle/element.py, restating
+// NavierStokesChannelFlow.py:160-172 (Stokes) and :220-251 + :46 (NS + exact
+// Gateaux derivative).
+
+#define QA 0.1381966011250105
+#define QB 0.5854101966249685
+
+constexpr int EL_TPB = 256;
+constexpr int EL_TETS = EL_TETS_PER_BLOCK;
+
+struct TetLds {
+    double X[12];
+    double W[16];
+    double GW[16];     // (g - w) on Dirichlet dofs, 0 elsewhere  -> lifting (:65)
+    double g[12];      // grad phi_a  [a][j]
+    double gu[9];      // grad u      [i][j]
+    double guga[12];   // (grad u) g_a [a][i]
+    double sc[4];      // wd = |detJ|/24, div u, tr G, h^2 (Stokes)
+    double q[4][16];   // per point: u[3], p, tau, nuL, Gu[3], conv[3], s[4]
+};
+
+__device__ __forceinline__ double phi_q(int q, int a) { return q == a ? QB : QA; }
+
+template <int FORM, bool corrected>
+__global__ __launch_bounds__(EL_TPB) void k_element(int64_t n_tets, const int32_t* __restrict__ tets,
+                                                    const double* __restrict__ pts,
+                                                    const double* __restrict__ w,
+                                                    const uint8_t* __restrict__ bc_mask,
+                                                    const double* __restrict__ bc_val, double nu,
+                                                    int store_K, double* __restrict__ Ke,
+                                                    double* __restrict__ Fe) {
+    __shared__ TetLds sh[EL_TETS];
+    __shared__ double tile[EL_TPB * 17];
+
+    const int tid = threadIdx.x;
+    const int tl = tid >> 4;            // tet within workgroup
+    const int l = tid & 15;             // lane within tet
+    const int a = l >> 2, b = l & 3;
+    const int64_t t = (int64_t)blockIdx.x * EL_TETS + tl;
+    const bool live = t < n_tets;
+    TetLds& S = sh[tl];
+
+    // ---- stage nodal data ----------------------------------------------------
+    if (live) {
+        const int32_t na = tets[4 * t + a];
+        const int64_t dof = 4 * (int64_t)na + b;      // lane l <-> local dof 4a+c with c=b
+        const double wv = w ? w[dof] : 0.0;
+        S.W[l] = wv;
+        S.GW[l] = bc_mask[dof] ? (bc_val[dof] - wv) : 0.0;
+        if (l < 12) {
+            const int32_t nv = tets[4 * t + l / 3];
+            S.X[l] = pts[3 * (int64_t)nv + l % 3];
+        }
+    }
+    __syncthreads();
+
+    // ---- geometry + per-point scalars (lanes 0..3 = quadrature points) -------
+    if (live && l < 4) {
+        const int q = l;
+        const double* X = S.X;
+        double J[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J[i][0] = X[3 + i] - X[i];
+            J[i][1] = X[6 + i] - X[i];
+            J[i][2] = X[9 + i] - X[i];
+        }
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double id = 1.0 / det;
+        double K[3][3];                                   // K = J^-1
+        K[0][0] = c00 * id;
+        K[1][0] = c01 * id;
+        K[2][0] = c02 * id;
+        K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+        K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+        K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+        K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+        K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+        K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+        double g[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            g[1][j] = K[0][j];
+            g[2][j] = K[1][j];
+            g[3][j] = K[2][j];
+            g[0][j] = -(K[0][j] + K[1][j] + K[2][j]);
+        }
+        double G[3][3];                                   // G = K^T K   (:235)
+        double trG = 0.0, GG = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                G[i][j] = K[0][i] * K[0][j] + K[1][i] * K[1][j] + K[2][i] * K[2][j];
+                GG += G[i][j] * G[i][j];
+                if (i == j) trG += G[i][j];
+            }
+        const double* W = S.W;
+        double gu[3][3], gp[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gp[j] = W[3] * g[0][j] + W[7] * g[1][j] + W[11] * g[2][j] + W[15] * g[3][j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                gu[i][j] = W[i] * g[0][j] + W[4 + i] * g[1][j] + W[8 + i] * g[2][j] + W[12 + i] * g[3][j];
+        }
+        const double divu = gu[0][0] + gu[1][1] + gu[2][2];
+        if (q == 0) {
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    S.g[3 * aa + j] = g[aa][j];
+                    // (grad u) g_a, or for the corrected form g_a^T (grad u) (the transpose contraction)
+                    S.guga[3 * aa + j] = corrected
+                        ? (g[aa][0] * gu[0][j] + g[aa][1] * gu[1][j] + g[aa][2] * gu[2][j])
+                        : (gu[j][0] * g[aa][0] + gu[j][1] * g[aa][1] + gu[j][2] * g[aa][2]);
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) S.gu[3 * i + j] = gu[i][j];
+            double h2 = 0.0;                               // CellDiameter^2 (:168)
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                for (int bb = aa + 1; bb < 4; ++bb) {
+                    const double d0 = X[3 * aa] - X[3 * bb], d1 = X[3 * aa + 1] - X[3 * bb + 1],
+                                 d2 = X[3 * aa + 2] - X[3 * bb + 2];
+                    h2 = fmax(h2, d0 * d0 + d1 * d1 + d2 * d2);
+                }
+            S.sc[0] = fabs(det) * (1.0 / 24.0);
+            S.sc[1] = divu;
+            S.sc[2] = trG;
+            S.sc[3] = h2;
+        }
+        if (FORM == SNS_FORM_NS) {
+            double u[3], p = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u[i] = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const double ph = phi_q(q, aa);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) u[i] += ph * W[4 * aa + i];
+                p += ph * W[4 * aa + 3];
+            }
+            double Gu[3], conv[3], r[3];
+            double uGu = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Gu[i] = G[i][0] * u[0] + G[i][1] * u[1] + G[i][2] * u[2];
+                uGu += u[i] * Gu[i];
+                conv[i] = gu[i][0] * u[0] + gu[i][1] * u[1] + gu[i][2] * u[2];          // (u.grad)u :243
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)                       // res_M :241  (reference: dot(u, grad(u)) = (grad u)^T u)
+                r[j] = (corrected ? conv[j] : (gu[0][j] * u[0] + gu[1][j] * u[1] + gu[2][j] * u[2])) + gp[j];
+            const double tau = 1.0 / sqrt(uGu + 36.0 * nu * nu * GG);                     // :237-238
+            const double nuL = 1.0 / (trG * tau);                                        // :249
+            double* Q = S.q[q];
+            Q[0] = u[0]; Q[1] = u[1]; Q[2] = u[2]; Q[3] = p; Q[4] = tau; Q[5] = nuL;
+            Q[6] = Gu[0]; Q[7] = Gu[1]; Q[8] = Gu[2];
+            Q[9] = conv[0]; Q[10] = conv[1]; Q[11] = conv[2];
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) Q[12 + aa] = r[0] * g[aa][0] + r[1] * g[aa][1] + r[2] * g[aa][2];
+        }
+    }
+    __syncthreads();
+
+    // ---- block (a,b): accumulate over quadrature points -----------------------
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    double Rl[4] = {0.0, 0.0, 0.0, 0.0};                 // residual of local node a (lanes with b==0 only, NS)
+    if (live) {
+        const double ga0 = S.g[3 * a], ga1 = S.g[3 * a + 1], ga2 = S.g[3 * a + 2];
+        const double gb0 = S.g[3 * b], gb1 = S.g[3 * b + 1], gb2 = S.g[3 * b + 2];
+        const double ga[3] = {ga0, ga1, ga2}, gb[3] = {gb0, gb1, gb2};
+        const double gab = ga0 * gb0 + ga1 * gb1 + ga2 * gb2;
+        const double wd = S.sc[0], divu = S.sc[1], trG = S.sc[2];
+        if (FORM == SNS_FORM_STOKES) {
+            const double vol = 4.0 * wd;
+            const double muT = 0.2 * S.sc[3];                                            // :169
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                acc[5 * i] = vol * gab;                     // (grad u, grad v)
+                acc[4 * i + 3] = -wd * ga[i];               // -(p, div v)   int phi_b = vol/4 = wd
+                acc[12 + i] = wd * gb[i];                   // +(div u, q)
+            }
+            acc[15] = muT * vol * gab;                      // mu_T (grad p, grad q)
+        } else {
+            const double* gum = S.gu;
+            const double gg0 = S.guga[3 * a], gg1 = S.guga[3 * a + 1], gg2 = S.guga[3 * a + 2];
+            const double guga_a[3] = {gg0, gg1, gg2};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* Q = S.q[q];
+                const double pa = phi_q(q, a), pb = phi_q(q, b);
+                const double u[3] = {Q[0], Q[1], Q[2]};
+                const double tau = Q[4], nuL = Q[5];
+                const double Gu[3] = {Q[6], Q[7], Q[8]};
+                const double sa = Q[12 + a];
+                const double ugb = u[0] * gb0 + u[1] * gb1 + u[2] * gb2;
+                const double uga = u[0] * ga0 + u[1] * ga1 + u[2] * ga2;
+                // coefficient of delta_ij; convection phi_a (g_b.u); viscous; SUPG tau s_a phi_b
+                // (corrected form: test function (u.grad)v = (u.g_a) e_i, so tau*(r.e_i) pieces differ, see below)
+                double cu[3], cg[3];
+                const double t3 = tau * tau * tau;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double dtau = -t3 * pb * Gu[j];                         // d tau / d u_(b,j)
+                    const double dnuL = (tau / trG) * pb * Gu[j];                 // d nu_L
+                    cg[j] = dnuL * divu + nuL * gb[j];
+                    if (!corrected) {
+                        // d(r.g_a) = u_j g_a.g_b + phi_b ((grad u) g_a)_j
+                        cu[j] = dtau * sa + tau * (u[j] * gab + pb * guga_a[j]);
+                    } else {
+                        cu[j] = dtau;                                              // used differently below
+                    }
+                }
+                if (!corrected) {
+                    const double A1 = pa * ugb + nu * gab + tau * sa * pb;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            acc[4 * i + j] += pa * pb * gum[3 * i + j] + u[i] * cu[j] + ga[i] * cg[j];
+                        acc[5 * i] += A1;
+                        acc[4 * i + 3] += -pb * ga[i] + tau * u[i] * gab;        // J[(a,i),(b,p)]
+                        acc[12 + i] += pa * gb[i] + cu[i];                       // J[(a,p),(b,j)]
+                    }
+                    acc[15] += tau * gab;
+                } else {
+                    // corrected variant: res_M = (u.grad)u + grad p ; SUPG test = (u.grad)v + grad q
+                    //   R[(a,i)] += tau (u.g_a) r_i ; R[(a,p)] += tau (r.g_a)
+                    // with r = conv + gp: d r_i/d u_(b,j) = delta_ij (u.g_b) + phi_b gu[i][j]
+                    const double r0 = Q[9] + 0.0, r1 = Q[10], r2 = Q[11];
+                    // r (without grad p) is conv; s_a already holds r.g_a incl. grad p; recover r_i:
+                    // S.q stores conv and s only, so rebuild r_i = conv_i + gp_i via gp = sum_a P_a g_a
+                    double gp[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        gp[j] = S.W[3] * S.g[j] + S.W[7] * S.g[3 + j] + S.W[11] * S.g[6 + j] + S.W[15] * S.g[9 + j];
+                    const double r[3] = {r0 + gp[0], r1 + gp[1], r2 + gp[2]};
+                    const double A1 = pa * ugb + nu * gab + tau * uga * ugb;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            acc[4 * i + j] += pa * pb * gum[3 * i + j]
+                                + cu[j] * uga * r[i]                               // d tau
+                                + tau * pb * ga[j] * r[i]                          // d (u.g_a)
+                                + tau * uga * pb * gum[3 * i + j]                  // d r_i (phi_b gu_ij)
+                                + ga[i] * cg[j];
+                        acc[5 * i] += A1;
+                        acc[4 * i + 3] += -pb * ga[i] + tau * uga * gb[i];       // d r_i / d p_b = g_b[i]
+                        // continuity row: phi_a g_b[j] + d(tau r.g_a)
+                        acc[12 + i] += pa * gb[i] + cu[i] * sa + tau * (ugb * ga[i] + pb * guga_a[i]);
+                    }
+                    acc[15] += tau * gab;
+                }
+                if (b == 0) {                               // residual of node a
+                    const double p = Q[3];
+                    if (!corrected) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            Rl[i] += Q[9 + i] * pa + nu * guga_a[i] - p * ga[i] + tau * u[i] * sa + nuL * divu * ga[i];
+                    } else {
+                        double gp[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            gp[j] = S.W[3] * S.g[j] + S.W[7] * S.g[3 + j] + S.W[11] * S.g[6 + j] + S.W[15] * S.g[9 + j];
+                        // nu (grad u):(grad v) needs (grad u) g_a regardless of the variant
+                        const double vg[3] = {gum[0] * ga0 + gum[1] * ga1 + gum[2] * ga2,
+                                              gum[3] * ga0 + gum[4] * ga1 + gum[5] * ga2,
+                                              gum[6] * ga0 + gum[7] * ga1 + gum[8] * ga2};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            Rl[i] += Q[9 + i] * pa + nu * vg[i] - p * ga[i] + tau * uga * (Q[9 + i] + gp[i]) +
+                                     nuL * divu * ga[i];
+                    }
+                    Rl[3] += pa * divu + tau * sa;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= wd;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Rl[c] *= wd;
+        }
+    }
+
+    // ---- element residual: Fe[a][c] = R[a][c] + sum_b block(a,b) * (g-w)_b   (lifting :65)
+    // Stokes: R = sum_b block(a,b) * w_b (linear form), so the same reduction with (w + (g-w)).
+    if (Fe) {
+        double part[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const double xv = (FORM == SNS_FORM_STOKES) ? (S.W[4 * b + d] + S.GW[4 * b + d]) : S.GW[4 * b + d];
+                s += acc[4 * c + d] * xv;
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            part[c] = s + Rl[c];
+        }
+        if (live && b == 0) {
+            double* o = Fe + (4 * t + a) * 4;
+            o[0] = part[0]; o[1] = part[1]; o[2] = part[2]; o[3] = part[3];
+        }
+    }
+
+    // ---- transpose 256 blocks through LDS, store 1 KiB per wave instruction ----
+    if (store_K) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[tid * 17 + e] = acc[e];
+        __syncthreads();
+        const int64_t base = (int64_t)blockIdx.x * (EL_TETS * 256);
+        const int64_t lim = n_tets * 256;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = i * EL_TPB + tid;
+            const int64_t gidx = base + idx;
+            if (gidx < lim) Ke[gidx] = tile[(idx >> 4) * 17 + (idx & 15)];
+        }
+    }
+}
+
+#define SNS_INST_ELEMENT(F, C)                                                                              \
+    template __global__ void k_element<F, C>(int64_t, const int32_t*, const double*, const double*,            \
+                                             const uint8_t*, const double*, double, int, double*, double*);
+SNS_INST_ELEMENT(SNS_FORM_STOKES, false)
+SNS_INST_ELEMENT(SNS_FORM_NS, false)
+SNS_INST_ELEMENT(SNS_FORM_NS, true)
+
+// BSR slot <- sum over its contributing element blocks (fixed order => bitwise
+// reproducible), Dirichlet rows AND columns zeroed, unit diagonal (:74).
+// 16 lanes per slot, lane = entry (c,d): each contribution is one 128-B line.
+__global__ __launch_bounds__(256) void k_gather_matrix(int64_t nnzb, const int64_t* __restrict__ c_ptr,
+                                                       const int32_t* __restrict__ c_idx,
+                                                       const int32_t* __restrict__ slot_row,
+                                                       const int32_t* __restrict__ colind,
+                                                       const uint8_t* __restrict__ bc_mask,
+                                                       const double* __restrict__ Ke, double* __restrict__ vals) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 4;
+    const int e = (int)(gid & 15);
+    if (s >= nnzb) return;
+    const int64_t k0 = c_ptr[s], k1 = c_ptr[s + 1];
+    double a0 = 0.0, a1 = 0.0;
+    int64_t k = k0;
+    for (; k + 1 < k1; k += 2) {
+        a0 += Ke[(int64_t)c_idx[k] * 16 + e];
+        a1 += Ke[(int64_t)c_idx[k + 1] * 16 + e];
+    }
+    if (k < k1) a0 += Ke[(int64_t)c_idx[k] * 16 + e];
+    double v = a0 + a1;
+    const int32_t row = slot_row[s], col = colind[s];
+    const int c = e >> 2, d = e & 3;
+    if (bc_mask[4 * (int64_t)row + c] | bc_mask[4 * (int64_t)col + d]) v = (row == col && c == d) ? 1.0 : 0.0;
+    vals[s * 16 + e] = v;
+}
+
+// node residual <- sum of incident element residuals; F_B = w_B - g (:67)
+__global__ __launch_bounds__(256) void k_gather_residual(int32_t n_rows, const int64_t* __restrict__ nt_ptr,
+                                                         const int32_t* __restrict__ nt_idx,
+                                                         const uint8_t* __restrict__ bc_mask,
+                                                         const double* __restrict__ bc_val,
+                                                         const double* __restrict__ w,
+                                                         const double* __restrict__ Fe, double* __restrict__ F) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (i >= n_rows) return;
+    double s = 0.0;
+    for (int64_t k = nt_ptr[i]; k < nt_ptr[i + 1]; ++k) s += Fe[(int64_t)nt_idx[k] * 4 + c];
+    const int64_t dof = 4 * i + c;
+    if (bc_mask[dof]) s = (w ? w[dof] : 0.0) - bc_val[dof];
+    F[dof] = s;
+}
+
+// ============================================================================
+// K2: BSR4 SpMV.  8 lanes per block row: lane t -> (r = t>>1, half = t&1) loads
+// 16 B (two doubles of block row r) per block, so one 8-lane group streams a
+// whole 128-B block per instruction and a wave streams 8 consecutive rows.
+// Workgroups are remapped so that each XCD walks one contiguous eighth of the
+// matrix (its private L2 then holds the x entries of ITS rows only).
+// ============================================================================
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                              const int32_t* __restrict__ colind,
+                                              const double* __restrict__ vals, const double* __restrict__ x,
+                                              double* __restrict__ y, const double* __restrict__ bvec,
+                                              const double* __restrict__ dinv, double omega,
+                                              const double* __restrict__ dotw, double* __restrict__ partial) {
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int t = lane & 7;
+    const int r = t >> 1, hf = t & 1;
+    const int32_t row = (blk * 4 + (tid >> 6)) * 8 + (lane >> 3);
+    double acc0 = 0.0, acc1 = 0.0;
+    const bool live = row < n_rows;
+    if (live) {
+        const int32_t s = rowptr[row], e = rowptr[row + 1];
+        const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals) + ((int64_t)s * 8 + r * 2 + hf);
+        int32_t k = s;
+        for (; k + 3 < e; k += 4) {
+            const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
+            const double2 a0 = vp[0], a1 = vp[8], a2 = vp[16], a3 = vp[24];
+            const double2 x0 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c0 + 2 * hf);
+            const double2 x1 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c1 + 2 * hf);
+            const double2 x2 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c2 + 2 * hf);
+            const double2 x3 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c3 + 2 * hf);
+            acc0 += a0.x * x0.x + a0.y * x0.y;
+            acc1 += a1.x * x1.x + a1.y * x1.y;
+            acc0 += a2.x * x2.x + a2.y * x2.y;
+            acc1 += a3.x * x3.x + a3.y * x3.y;
+            vp += 32;
+        }
+        for (; k < e; ++k) {
+            const int32_t c0 = colind[k];
+            const double2 a0 = vp[0];
+            const double2 x0 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c0 + 2 * hf);
+            acc0 += a0.x * x0.x + a0.y * x0.y;
+            vp += 8;
+        }
+    }
+    double acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1);                      // both halves now hold (A x)[4*row + r]
+    if (MODE == SPMV_AX) {
+        if (live && hf == 0) y[4 * (int64_t)row + r] = acc;
+    } else if (MODE == SPMV_B_MINUS_AX) {
+        if (live && hf == 0) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
+    } else if (MODE == SPMV_JACOBI) {
+        // y = x + omega * Dinv (b - A x): residual of row component r lives on lanes (r,*);
+        // fetch the 4 components of this row's residual with shuffles inside the 8-lane group.
+        const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
+        const int gbase = lane & ~7;
+        const double r0 = __shfl(res, gbase + 0), r1 = __shfl(res, gbase + 2), r2 = __shfl(res, gbase + 4),
+                     r3 = __shfl(res, gbase + 6);
+        if (live && hf == 0) {
+            const double* D = dinv + 16 * (int64_t)row + 4 * r;
+            y[4 * (int64_t)row + r] =
+                x[4 * (int64_t)row + r] + omega * (D[0] * r0 + D[1] * r1 + D[2] * r2 + D[3] * r3);
+        }
+    } else if (MODE == SPMV_AX_DOT) {
+        // y = A x and partial[block] = sum_rows dotw . y   (fused <r^, A p> of BiCGStab)
+        double pr = 0.0;
+        if (live && hf == 0) {
+            y[4 * (int64_t)row + r] = acc;
+            pr = acc * dotw[4 * (int64_t)row + r];
+        }
+        __shared__ double red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) red[tid >> 6] = pr;
+        __syncthreads();
+        if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+template __global__ void k_spmv<SPMV_AX>(int32_t, const int32_t*, const int32_t*, const double*, const double*,
+                                         double*, const double*, const double*, double, const double*, double*);
+template __global__ void k_spmv<SPMV_B_MINUS_AX>(int32_t, const int32_t*, const int32_t*, const double*,
+                                                 const double*, double*, const double*, const double*, double,
+                                                 const double*, double*);
+template __global__ void k_spmv<SPMV_JACOBI>(int32_t, const int32_t*, const int32_t*, const double*,
+                                             const double*, double*, const double*, const double*, double,
+                                             const double*, double*);
+template __global__ void k_spmv<SPMV_AX_DOT>(int32_t, const int32_t*, const int32_t*, const double*,
+                                             const double*, double*, const double*, const double*, double,
+                                             const double*, double*);
+
+// ============================================================================
+// K3: 4x4 diagonal-block inverse (Gauss-Jordan, partial pivoting), one thread per node
+// ============================================================================
+__global__ __launch_bounds__(256) void k_dinv(int32_t n, const int32_t* __restrict__ diag,
+                                              const double* __restrict__ vals, double* __restrict__ dinv) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[4][8];
+    const double* src = vals + 16 * (int64_t)diag[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            A[r][c] = src[4 * r + c];
+            A[r][4 + c] = (r == c) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) {
+            const double v = fabs(A[r][k]);
+            if (v > best) { best = v; p = r; }
+        }
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r)
+            if (r == p) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const double tmp = A[k][c]; A[k][c] = A[r][c]; A[r][c] = tmp; }
+            }
+        const double ip = (A[k][k] != 0.0) ? 1.0 / A[k][k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) A[k][c] *= ip;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r != k) {
+                const double f = A[r][k];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) A[r][c] -= f * A[k][c];
+            }
+    }
+    double* dst = dinv + 16 * (int64_t)i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[4 * r + c] = A[r][4 + c];
+}
+
+// z = omega * Dinv r   (first Jacobi sweep from a zero guess / plain block-Jacobi PC)
+__global__ __launch_bounds__(256) void k_bjacobi(int32_t n, const double* __restrict__ dinv,
+                                                 const double* __restrict__ r, double omega,
+                                                 double* __restrict__ z) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (i >= n) return;
+    const double* D = dinv + 16 * i + 4 * c;
+    const double* rr = r + 4 * i;
+    z[4 * i + c] = omega * (D[0] * rr[0] + D[1] * rr[1] + D[2] * rr[2] + D[3] * rr[3]);
+}
+
+// ============================================================================
+// K4: vector kernels.  Reductions are two-stage and deterministic: each block
+// writes its partial sums to `partial[blockIdx * nred + k]`; k_reduce_final sums
+// them in a fixed order into out[k].
+// ============================================================================
+constexpr int VEC_TPB = 256;
+
+template <int NRED>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NRED], double* partial) {
+    __shared__ double red[NRED][VEC_TPB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) {
+        double s = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[k][wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NRED) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < VEC_TPB / 64; ++w) s += red[threadIdx.x][w];
+        partial[(int64_t)blockIdx.x * NRED + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_final(int nblocks, int nred, const double* __restrict__ partial,
+                                                      double* __restrict__ out) {
+    // one block; thread k < nred sums column k over blocks (strided by 64 lanes per column)
+    __shared__ double red[256];
+    const int k = blockIdx.x;                   // one block per reduced quantity
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[(int64_t)b * nred + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = red[0];
+}
+
+// generic: out[0] = x.y, out[1] = y.y  (n = number of doubles reduced over)
+__global__ __launch_bounds__(256) void k_dot2(int64_t n, const double* __restrict__ x,
+                                              const double* __restrict__ y, double* __restrict__ partial) {
+    double v[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = x[i], b = y[i];
+        v[0] += a * b;
+        v[1] += b * b;
+    }
+    block_reduce_store<2>(v, partial);
+}
+
+// y = a*x + b*y
+__global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double* __restrict__ x, double b,
+                                               double* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+
+// z = a*x + b*y + c*z
+__global__ __launch_bounds__(256) void k_axpbypcz(int64_t n, double a, const double* __restrict__ x, double b,
+                                                  const double* __restrict__ y, double c,
+                                                  double* __restrict__ z) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        z[i] = a * x[i] + b * y[i] + (c == 0.0 ? 0.0 : c * z[i]);
+}
+
+// BiCGStab: p = r + beta * (p - omega * v)
+__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* __restrict__ r, double beta, double omega,
+                                                const double* __restrict__ v, double* __restrict__ p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+// BiCGStab: s = r - alpha v ; partial = (s.s)
+__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restrict__ r, double alpha,
+                                                const double* __restrict__ v, double* __restrict__ s,
+                                                double* __restrict__ partial) {
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double sv = r[i] - alpha * v[i];
+        s[i] = sv;
+        acc[0] += sv * sv;
+    }
+    block_reduce_store<1>(acc, partial);
+}
+
+// BiCGStab: x += alpha ph + omega sh ; r = s - omega t ; partial = (rhat.r, r.r)
+__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, double alpha, const double* __restrict__ ph,
+                                                 double omega, const double* __restrict__ sh,
+                                                 const double* __restrict__ s, const double* __restrict__ t,
+                                                 const double* __restrict__ rhat, double* __restrict__ x,
+                                                 double* __restrict__ r, double* __restrict__ partial) {
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * ph[i] + omega * sh[i];
+        const double rv = s[i] - omega * t[i];
+        r[i] = rv;
+        acc[0] += rhat[i] * rv;
+        acc[1] += rv * rv;
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// GMRES: h[k] = V_k . w for k < nv (chunks of 8 basis vectors per pass over w)
+__global__ __launch_bounds__(256) void k_multi_dot8(int64_t n, int nv, const double* __restrict__ V, int64_t ldv,
+                                                    const double* __restrict__ w, double* __restrict__ partial) {
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double wv = w[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nv) acc[k] += V[k * ldv + i] * wv;
+    }
+    block_reduce_store<8>(acc, partial);
+}
+
+// GMRES: w -= sum_k h[k] V_k (k < nv <= 8, h on device) ; partial = (w.w) when want_norm
+__global__ __launch_bounds__(256) void k_multi_axpy8(int64_t n, int nv, const double* __restrict__ V, int64_t ldv,
+                                                     const double* __restrict__ h, double sign,
+                                                     double* __restrict__ w, double* __restrict__ partial) {
+    double hk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hk[k] = (k < nv) ? sign * h[k] : 0.0;
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double wv = w[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nv) wv += hk[k] * V[k * ldv + i];
+        w[i] = wv;
+        acc[0] += wv * wv;
+    }
+    if (partial) block_reduce_store<1>(acc, partial);
+}
+
+__global__ __launch_bounds__(256) void k_scale_copy(int64_t n, double a, const double* x, double* y) {  // x may alias y
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i];
+}
+
+// ============================================================================
+// AMG kernels (plain aggregation, 4 dofs per aggregate)
+// ============================================================================
+// bc[I] = sum_{i in I} free_i * r[i]     (restriction = P0^T, gather => deterministic)
+__global__ __launch_bounds__(256) void k_restrict(int32_t nc, const int32_t* __restrict__ m_ptr,
+                                                  const int32_t* __restrict__ m_idx,
+                                                  const uint8_t* __restrict__ free_mask,
+                                                  const double* __restrict__ r, double* __restrict__ bc) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t I = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (I >= nc) return;
+    double s = 0.0;
+    for (int32_t k = m_ptr[I]; k < m_ptr[I + 1]; ++k) {
+        const int64_t d = 4 * (int64_t)m_idx[k] + c;
+        if (!free_mask || free_mask[d]) s += r[d];
+    }
+    bc[4 * I + c] = s;
+}
+
+// x[i] += free_i * xc[agg[i]]
+__global__ __launch_bounds__(256) void k_prolong_add(int32_t n, const int32_t* __restrict__ agg,
+                                                     const uint8_t* __restrict__ free_mask,
+                                                     const double* __restrict__ xc, double* __restrict__ x) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (i >= n) return;
+    const int32_t I = agg[i];
+    if (I < 0) return;
+    if (free_mask && !free_mask[4 * i + c]) return;
+    x[4 * i + c] += xc[4 * (int64_t)I + c];
+}
+
+// Galerkin coarse operator A_c = P0^T A P0 as a gather: coarse slot <- sum of fine
+// slots; entries whose fine row/col dof is excluded from the transfer are skipped;
+// coarse dofs with no free fine dof get a unit diagonal.
+__global__ __launch_bounds__(256) void k_galerkin(int64_t nnzb_c, const int64_t* __restrict__ r_ptr,
+                                                  const int32_t* __restrict__ r_idx,
+                                                  const int32_t* __restrict__ slot_row_f,
+                                                  const int32_t* __restrict__ colind_f,
+                                                  const uint8_t* __restrict__ free_mask,
+                                                  const double* __restrict__ vals_f,
+                                                  const int32_t* __restrict__ slot_row_c,
+                                                  const int32_t* __restrict__ colind_c,
+                                                  const uint8_t* __restrict__ empty_c,
+                                                  double* __restrict__ vals_c) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 4;
+    const int e = (int)(gid & 15);
+    if (s >= nnzb_c) return;
+    const int c = e >> 2, d = e & 3;
+    double v = 0.0;
+    for (int64_t k = r_ptr[s]; k < r_ptr[s + 1]; ++k) {
+        const int32_t fs = r_idx[k];
+        if (free_mask) {
+            const int32_t fr = slot_row_f[fs], fc = colind_f[fs];
+            if (!free_mask[4 * (int64_t)fr + c] || !free_mask[4 * (int64_t)fc + d]) continue;
+        }
+        v += vals_f[(int64_t)fs * 16 + e];
+    }
+    if (empty_c && slot_row_c[s] == colind_c[s] && c == d && empty_c[4 * (int64_t)slot_row_c[s] + c]) v = 1.0;
+    vals_c[s * 16 + e] = v;
+}
+
+// empty_c[4I+c] = 1 if aggregate I has no free fine dof of component c
+__global__ __launch_bounds__(256) void k_empty_coarse(int32_t nc, const int32_t* __restrict__ m_ptr,
+                                                      const int32_t* __restrict__ m_idx,
+                                                      const uint8_t* __restrict__ free_mask,
+                                                      uint8_t* __restrict__ empty_c) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t I = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (I >= nc) return;
+    int any = 0;
+    for (int32_t k = m_ptr[I]; k < m_ptr[I + 1]; ++k) any |= free_mask[4 * (int64_t)m_idx[k] + c];
+    empty_c[4 * I + c] = any ? 0 : 1;
+}
+
+// dense N x N (N = 4n) copy of a small BSR matrix
+__global__ __launch_bounds__(256) void k_bsr_to_dense(int32_t n, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ colind,
+                                                      const double* __restrict__ vals, double* __restrict__ D) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 4;
+    const int e = (int)(gid & 15);
+    if (s >= rowptr[n]) return;
+    // find row by linear search over a tiny matrix
+    int32_t row = 0;
+    while (rowptr[row + 1] <= s) ++row;
+    const int N = 4 * n;
+    D[(int64_t)(4 * row + (e >> 2)) * N + 4 * colind[s] + (e & 3)] = vals[s * 16 + e];
+}
+
+// In-place Gauss-Jordan inverse with partial pivoting, ONE workgroup, matrix in
+// global memory (L2-resident: N <= 160).  Only used on the coarsest AMG level.
+__global__ __launch_bounds__(1024) void k_dense_inverse(int N, double* __restrict__ A, int* __restrict__ piv,
+                                                        int* __restrict__ singular) {
+    __shared__ int s_p;
+    __shared__ double s_best[1024];
+    __shared__ int s_arg[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k = 0; k < N; ++k) {
+        // pivot search in column k, rows >= k
+        double best = -1.0;
+        int arg = k;
+        for (int r = k + tid; r < N; r += nt) {
+            const double v = fabs(A[(int64_t)r * N + k]);
+            if (v > best) { best = v; arg = r; }
+        }
+        s_best[tid] = best;
+        s_arg[tid] = arg;
+        __syncthreads();
+        for (int o = nt / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                if (s_best[tid + o] > s_best[tid] ||
+                    (s_best[tid + o] == s_best[tid] && s_arg[tid + o] < s_arg[tid])) {
+                    s_best[tid] = s_best[tid + o];
+                    s_arg[tid] = s_arg[tid + o];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            s_p = s_arg[0];
+            piv[k] = s_arg[0];
+            if (!(s_best[0] > 0.0)) *singular = 1;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k)
+            for (int c = tid; c < N; c += nt) {
+                const double tmp = A[(int64_t)k * N + c];
+                A[(int64_t)k * N + c] = A[(int64_t)p * N + c];
+                A[(int64_t)p * N + c] = tmp;
+            }
+        __threadfence_block();
+        __syncthreads();
+        const double pivv = A[(int64_t)k * N + k];
+        const double ip = (pivv != 0.0) ? 1.0 / pivv : 0.0;
+        __syncthreads();
+        // scale pivot row; A[k][k] <- 1/pivot
+        for (int c = tid; c < N; c += nt) A[(int64_t)k * N + c] = (c == k) ? ip : A[(int64_t)k * N + c] * ip;
+        __threadfence_block();
+        __syncthreads();
+        // eliminate column k from all other rows
+        for (int idx = tid; idx < N * N; idx += nt) {
+            const int r = idx / N, c = idx - r * N;
+            if (r == k) continue;
+            const double f = A[(int64_t)r * N + k];
+            // every thread of row r needs the OLD A[r][k]; column k itself is rewritten last (below)
+            if (c != k) A[(int64_t)r * N + c] -= f * A[(int64_t)k * N + c];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int r = tid; r < N; r += nt)
+            if (r != k) A[(int64_t)r * N + k] = -A[(int64_t)r * N + k] * ip;
+        __threadfence_block();
+        __syncthreads();
+    }
+    // undo the row interchanges as column interchanges, in reverse order
+    for (int k = N - 1; k >= 0; --k) {
+        const int p = piv[k];
+        if (p != k)
+            for (int r = tid; r < N; r += nt) {
+                const double tmp = A[(int64_t)r * N + k];
+                A[(int64_t)r * N + k] = A[(int64_t)r * N + p];
+                A[(int64_t)r * N + p] = tmp;
+            }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// y = D x, dense N x N, one wave per row
+__global__ __launch_bounds__(256) void k_dense_matvec(int N, const double* __restrict__ D,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    double s = 0.0;
+    for (int c = lane; c < N; c += 64) s += D[(int64_t)row * N + c] * x[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] = s;
+}
+
+// ============================================================================
+// K7: halo pack / unpack (4 doubles per node)
+// ============================================================================
+__global__ __launch_bounds__(256) void k_pack(int32_t m, const int32_t* __restrict__ idx,
+                                              const double* __restrict__ x, double* __restrict__ buf) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 4 * (int64_t)m) return;
+    buf[gid] = x[4 * (int64_t)idx[gid >> 2] + (gid & 3)];
+}
+__global__ __launch_bounds__(256) void k_unpack(int32_t m, const int32_t* __restrict__ idx,
+                                                const double* __restrict__ buf, double* __restrict__ x) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 4 * (int64_t)m) return;
+    x[4 * (int64_t)idx[gid >> 2] + (gid & 3)] = buf[gid];
+}
+
+__global__ __launch_bounds__(256) void k_fill_slot_row(int32_t n, const int32_t* __restrict__ rowptr,
+                                                       int32_t* __restrict__ slot_row) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) slot_row[k] = i;
+}
+
+}  // namespace sns

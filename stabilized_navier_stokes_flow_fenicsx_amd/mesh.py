@@ -1,0 +1,320 @@
+"""Tetrahedral meshes with tagged boundary facets (host side, numpy).
+
+Plays the role of ``gmshio.model_to_mesh`` in the reference
+(NavierStokes/NavierStokesChannelFlow.py:111, StokesFlow/DuctStokesFlow.py:144):
+it hands the solver a tet connectivity whose *cell-local vertex order is kept
+exactly as given* (the metric tensor G of the stabilisation depends on which
+vertex is local vertex 0, NavierStokesChannelFlow.py:232-235) and a list of
+boundary triangles carrying integer physical tags.
+
+gmsh is not available offline, so besides a ``.msh`` (2.2 / 4.1 ASCII) reader
+this module has a deterministic structured box mesher (6 Kuhn tets per hex
+cell) that reproduces the reference geometries: the square duct
+``[0,L]x[-.5,.5]^2`` of DuctStokesFlow.py:36-124 (tags inlet=3, outlet=4,
+wall=5, :117), the 4x1x1 channel of image2gmsh3D.py:435-438 (tags inlet_1=1,
+inlet_2=2, outlet=3, wall=4) and the unit-cube cavity that extends
+LidDrivenNavierStokesFlow.py:29-43 to 3-D.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from itertools import permutations
+
+import numpy as np
+
+# physical tags of the reference scripts
+DUCT_TAGS = {"inlet": 3, "outlet": 4, "wall": 5}            # DuctStokesFlow.py:117
+CHANNEL_TAGS = {"inlet_1": 1, "inlet_2": 2, "outlet": 3, "wall": 4}  # image2gmsh3D.py:435-438
+CAVITY_TAGS = {"lid": 1, "wall": 2}
+
+
+@dataclass
+class TetMesh:
+    points: np.ndarray          # (N,3) float64
+    tets: np.ndarray            # (E,4) int32, cell-local order preserved
+    facets: np.ndarray          # (F,3) int32 boundary triangles
+    facet_tags: np.ndarray      # (F,) int32
+    name: str = "mesh"
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.points.shape[0])
+
+    @property
+    def num_tets(self) -> int:
+        return int(self.tets.shape[0])
+
+    @property
+    def num_dofs(self) -> int:
+        return 4 * self.num_nodes
+
+    def find(self, tag: int) -> np.ndarray:
+        """Facet indices carrying ``tag`` (mirror of dolfinx ``MeshTags.find``)."""
+        return np.nonzero(self.facet_tags == tag)[0]
+
+    def facet_nodes(self, tag: int) -> np.ndarray:
+        """Sorted unique vertex ids on facets tagged ``tag`` (the P1 analogue of
+        ``locate_dofs_topological(..., ft.find(tag))``)."""
+        return np.unique(self.facets[self.facet_tags == tag].ravel())
+
+
+# --------------------------------------------------------------------------- #
+# structured box -> 6 Kuhn tets per cell
+# --------------------------------------------------------------------------- #
+_KUHN = []
+for _perm in permutations(range(3)):
+    _v = [np.zeros(3, dtype=np.int64)]
+    for _ax in _perm:
+        _n = _v[-1].copy()
+        _n[_ax] += 1
+        _v.append(_n)
+    _KUHN.append(np.stack(_v))        # (4,3) corner offsets, v0=(0,0,0) ... v3=(1,1,1)
+_KUHN = np.stack(_KUHN)               # (6,4,3)
+
+
+def box_tet_mesh(lo, hi, cells, *, jitter: float = 0.0, seed: int = 1234,
+                 name: str = "box") -> tuple[np.ndarray, np.ndarray, tuple]:
+    """Nodes and Kuhn-6 tets of the box ``lo..hi`` with ``cells=(nx,ny,nz)``.
+
+    Node id = (i*(ny+1) + j)*(nz+1) + k  (x slowest), so that slabs in x are
+    contiguous id ranges (used by the multi-GPU slab partition) and the
+    neighbours of a node live in three adjacent yz-planes (SpMV locality).
+    Optional interior-node jitter (+-jitter*h) breaks structured
+    cache luck; boundary nodes never move.
+    """
+    nx, ny, nz = (int(c) for c in cells)
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    xs = np.linspace(lo[0], hi[0], nx + 1)
+    ys = np.linspace(lo[1], hi[1], ny + 1)
+    zs = np.linspace(lo[2], hi[2], nz + 1)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    if jitter > 0.0:
+        rng = np.random.default_rng(seed)
+        h = (hi - lo) / np.array([nx, ny, nz])
+        I, J, K = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+        interior = ((I > 0) & (I < nx) & (J > 0) & (J < ny) & (K > 0) & (K < nz)).ravel()
+        d = rng.uniform(-jitter, jitter, size=pts.shape) * h
+        pts[interior] += d[interior]
+
+    sy, sx = (nz + 1), (ny + 1) * (nz + 1)
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = (ci * sx + cj * sy + ck).ravel().astype(np.int64)     # node id of cell corner (0,0,0)
+    off = _KUHN[..., 0] * sx + _KUHN[..., 1] * sy + _KUHN[..., 2]  # (6,4)
+    tets = (base[:, None, None] + off[None]).reshape(-1, 4).astype(np.int32)
+    return pts, tets, (nx, ny, nz)
+
+
+def _boundary_facets(tets: np.ndarray) -> np.ndarray:
+    """Triangles that belong to exactly one tet (vertex order as in the tet)."""
+    f = np.concatenate([tets[:, [1, 2, 3]], tets[:, [0, 2, 3]], tets[:, [0, 1, 3]], tets[:, [0, 1, 2]]])
+    fs = np.sort(f.astype(np.int64), axis=1)
+    n = int(tets.max()) + 1
+    key = (fs[:, 0] * n + fs[:, 1]) * n + fs[:, 2]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.ones(ks.size, dtype=bool)
+    first[1:] = ks[1:] != ks[:-1]
+    last = np.ones(ks.size, dtype=bool)
+    last[:-1] = ks[1:] != ks[:-1]
+    return f[order[first & last]].astype(np.int32)
+
+
+def _tag_box_facets(pts, facets, lo, hi, tagger) -> np.ndarray:
+    c = pts[facets]                      # (F,3,3)
+    tol = 1e-9 * float(np.max(np.asarray(hi) - np.asarray(lo)))
+    on = {}
+    for ax, nm in enumerate("xyz"):
+        on[nm + "lo"] = np.all(np.abs(c[:, :, ax] - lo[ax]) < tol, axis=1)
+        on[nm + "hi"] = np.all(np.abs(c[:, :, ax] - hi[ax]) < tol, axis=1)
+    return tagger(on, c.mean(axis=1)).astype(np.int32)
+
+
+def duct_mesh(cells=(40, 10, 10), x_outlet: float = 4.0, *, jitter: float = 0.0,
+              tags: dict | None = None) -> TetMesh:
+    """Square duct [0,x_outlet] x [-.5,.5]^2 (DuctStokesFlow.py:36-124)."""
+    tags = dict(DUCT_TAGS if tags is None else tags)
+    lo, hi = (0.0, -0.5, -0.5), (float(x_outlet), 0.5, 0.5)
+    pts, tets, _ = box_tet_mesh(lo, hi, cells, jitter=jitter)
+    fac = _boundary_facets(tets)
+
+    def tagger(on, _cent):
+        t = np.full(fac.shape[0], tags["wall"])
+        t[on["xlo"]] = tags["inlet"]
+        t[on["xhi"]] = tags["outlet"]
+        return t
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    return TetMesh(pts, tets, fac, ft, name="duct",
+                   meta={"cells": tuple(cells), "lo": lo, "hi": hi, "tags": tags, "kind": "duct"})
+
+
+def channel_mesh(cells=(40, 10, 10), *, inner_half_width: float = 0.25, jitter: float = 0.0) -> TetMesh:
+    """4x1x1 two-stream channel with the tag set of image2gmsh3D.py:435-438.
+
+    The PNG->contour->OCC pipeline needs gmsh/skimage (absent offline); this is
+    the synthetic stand-in of SURVEY 8 config 4: inlet facets whose centroid
+    lies in the centred square of half width ``inner_half_width`` are the inner
+    stream (inlet_1), the remaining inlet facets the outer stream (inlet_2).
+    """
+    tags = dict(CHANNEL_TAGS)
+    lo, hi = (0.0, -0.5, -0.5), (4.0, 0.5, 0.5)
+    pts, tets, _ = box_tet_mesh(lo, hi, cells, jitter=jitter)
+    fac = _boundary_facets(tets)
+
+    def tagger(on, cent):
+        t = np.full(fac.shape[0], tags["wall"])
+        inner = (np.abs(cent[:, 1]) < inner_half_width) & (np.abs(cent[:, 2]) < inner_half_width)
+        t[on["xlo"] & inner] = tags["inlet_1"]
+        t[on["xlo"] & ~inner] = tags["inlet_2"]
+        t[on["xhi"]] = tags["outlet"]
+        return t
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    return TetMesh(pts, tets, fac, ft, name="channel",
+                   meta={"cells": tuple(cells), "lo": lo, "hi": hi, "tags": tags, "kind": "channel",
+                         "inner_half_width": inner_half_width})
+
+
+def cavity_mesh(n: int = 16, *, jitter: float = 0.0) -> TetMesh:
+    """Unit-cube lid-driven cavity, lid at y=1 (LidDrivenNavierStokesFlow.py:33-43 in 3-D)."""
+    tags = dict(CAVITY_TAGS)
+    lo, hi = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    pts, tets, _ = box_tet_mesh(lo, hi, (n, n, n), jitter=jitter)
+    fac = _boundary_facets(tets)
+
+    def tagger(on, _cent):
+        t = np.full(fac.shape[0], tags["wall"])
+        t[on["yhi"]] = tags["lid"]
+        return t
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    return TetMesh(pts, tets, fac, ft, name="cavity",
+                   meta={"cells": (n, n, n), "lo": lo, "hi": hi, "tags": tags, "kind": "cavity"})
+
+
+# --------------------------------------------------------------------------- #
+# gmsh .msh reader (ASCII 2.2 and 4.1), tets (type 4) + triangles (type 2)
+# --------------------------------------------------------------------------- #
+def read_msh(path: str) -> TetMesh:
+    """Read tets and tagged boundary triangles from a gmsh ASCII file.
+
+    Mirrors what ``gmshio.model_to_mesh`` / ``read_from_msh`` deliver to the
+    reference (NavierStokesChannelFlow.py:111, DFG_3D_Validation.py:79): only
+    entities in physical groups; the triangle tag is the physical-group id.
+    Cell-local vertex order is kept as written in the file.
+    """
+    with open(path, "r") as fh:
+        lines = fh.read().split("\n")
+    sec = {}
+    i = 0
+    while i < len(lines):
+        ln = lines[i].strip()
+        if ln.startswith("$") and not ln.startswith("$End"):
+            nm = ln[1:]
+            j = i + 1
+            while lines[j].strip() != "$End" + nm:
+                j += 1
+            sec[nm] = lines[i + 1:j]
+            i = j
+        i += 1
+    ver = float(sec["MeshFormat"][0].split()[0])
+    if int(sec["MeshFormat"][0].split()[1]) != 0:
+        raise ValueError("binary .msh files are not supported; write ASCII")
+    if ver < 3.0:
+        pts, ids, tris, tri_tags, tets = _read_msh2(sec)
+    else:
+        pts, ids, tris, tri_tags, tets = _read_msh4(sec)
+    remap = -np.ones(int(ids.max()) + 1, dtype=np.int64)
+    remap[ids] = np.arange(ids.size)
+    tets = remap[tets].astype(np.int32)
+    tris = remap[tris].astype(np.int32) if len(tris) else np.zeros((0, 3), np.int32)
+    used = np.zeros(ids.size, dtype=bool)
+    used[tets.ravel()] = True
+    if not used.all():                                  # drop nodes no tet references
+        new = -np.ones(ids.size, dtype=np.int64)
+        new[used] = np.arange(int(used.sum()))
+        pts, tets = pts[used], new[tets].astype(np.int32)
+        keep = np.all(new[tris] >= 0, axis=1) if len(tris) else np.zeros(0, bool)
+        tris, tri_tags = new[tris[keep]].astype(np.int32), np.asarray(tri_tags)[keep]
+    return TetMesh(np.ascontiguousarray(pts), np.ascontiguousarray(tets), np.ascontiguousarray(tris),
+                   np.asarray(tri_tags, dtype=np.int32), name=path, meta={"kind": "msh", "version": ver})
+
+
+def _read_msh2(sec):
+    nl = sec["Nodes"]
+    n = int(nl[0])
+    arr = np.array([ln.split() for ln in nl[1:1 + n]], dtype=np.float64)
+    ids, pts = arr[:, 0].astype(np.int64), arr[:, 1:4]
+    tris, tri_tags, tets = [], [], []
+    el = sec["Elements"]
+    for ln in el[1:1 + int(el[0])]:
+        t = ln.split()
+        et, ntag = int(t[1]), int(t[2])
+        phys = int(t[3]) if ntag > 0 else 0
+        nod = [int(v) for v in t[3 + ntag:]]
+        if et == 2 and phys > 0:
+            tris.append(nod)
+            tri_tags.append(phys)
+        elif et == 4:
+            tets.append(nod)
+    return pts, ids, np.array(tris, dtype=np.int64).reshape(-1, 3), tri_tags, np.array(tets, dtype=np.int64)
+
+
+def _read_msh4(sec):
+    ent_phys = {}                                       # (dim, tag) -> first physical tag
+    if "Entities" in sec:
+        el = sec["Entities"]
+        npnt, ncur, nsur, nvol = (int(v) for v in el[0].split())
+        k = 1 + npnt + ncur
+        for dim, cnt in ((2, nsur), (3, nvol)):
+            for ln in el[k:k + cnt]:
+                t = ln.split()
+                nphys = int(t[7])
+                if nphys > 0:
+                    ent_phys[(dim, int(t[0]))] = abs(int(t[8]))
+            k += cnt
+    nl = sec["Nodes"]
+    nblocks, nnodes = int(nl[0].split()[0]), int(nl[0].split()[1])
+    ids = np.empty(nnodes, dtype=np.int64)
+    pts = np.empty((nnodes, 3), dtype=np.float64)
+    k, w = 1, 0
+    for _ in range(nblocks):
+        cnt = int(nl[k].split()[3])
+        ids[w:w + cnt] = [int(v) for v in nl[k + 1:k + 1 + cnt]]
+        pts[w:w + cnt] = [[float(v) for v in ln.split()[:3]] for ln in nl[k + 1 + cnt:k + 1 + 2 * cnt]]
+        k += 1 + 2 * cnt
+        w += cnt
+    tris, tri_tags, tets = [], [], []
+    el = sec["Elements"]
+    nblocks = int(el[0].split()[0])
+    k = 1
+    for _ in range(nblocks):
+        dim, etag, et, cnt = (int(v) for v in el[k].split())
+        rows = [[int(v) for v in ln.split()[1:]] for ln in el[k + 1:k + 1 + cnt]]
+        if et == 2 and (2, etag) in ent_phys:
+            tris += rows
+            tri_tags += [ent_phys[(2, etag)]] * cnt
+        elif et == 4:
+            tets += rows
+        k += 1 + cnt
+    return pts, ids, np.array(tris, dtype=np.int64).reshape(-1, 3), tri_tags, np.array(tets, dtype=np.int64)
+
+
+def write_msh2(mesh: TetMesh, path: str) -> None:
+    """Write an ASCII gmsh-2.2 file (tests and mesh hand-over to other tools)."""
+    with open(path, "w") as fh:
+        fh.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % mesh.num_nodes)
+        for i, p in enumerate(mesh.points):
+            fh.write("%d %.17g %.17g %.17g\n" % (i + 1, p[0], p[1], p[2]))
+        fh.write("$EndNodes\n$Elements\n%d\n" % (len(mesh.facets) + mesh.num_tets))
+        e = 1
+        for f, t in zip(mesh.facets, mesh.facet_tags):
+            fh.write("%d 2 2 %d %d %d %d %d\n" % (e, t, t, f[0] + 1, f[1] + 1, f[2] + 1))
+            e += 1
+        for c in mesh.tets:
+            fh.write("%d 4 2 1 1 %d %d %d %d\n" % (e, c[0] + 1, c[1] + 1, c[2] + 1, c[3] + 1))
+            e += 1
+        fh.write("$EndElements\n")

@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's solve seam over the HIP C-ABI.
+
+Names, argument meaning and error behaviour follow
+NavierStokes/NavierStokesChannelFlow.py:
+  * ``NonlinearPDE_SNESProblem`` (:40-75)  -> F / J callbacks on device vectors
+  * ``solve_stokes_problem``     (:197-218)
+  * ``solve_navier_stokes``      (:268-312): returns ``(w, u, p)``, prints
+    iterations / reason / seconds (:297-299); non-convergence is NOT an error.
+All arithmetic happens in libsns.so (HIP); torch only owns device buffers and
+the stream.  There is no CPU fallback: constructing a ``FlowProblem`` without
+a GPU and the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FORM_NS, FORM_STOKES, SnsError, SnsOptions, SnsTimings, check, default_options
+from .bcs import DirichletSet
+from .mesh import TetMesh
+
+_FORMS = {"stokes": FORM_STOKES, "ns": FORM_NS, FORM_STOKES: FORM_STOKES, FORM_NS: FORM_NS}
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+@dataclass
+class KrylovResult:
+    its: int
+    reason: int
+    rnorm: float
+
+
+@dataclass
+class NewtonResult:
+    its: int
+    reason: int
+    ksp_its: int
+    fnorms: list
+    seconds: float
+
+
+class FlowProblem:
+    """Mesh + Dirichlet data + operator hierarchy on one GPU (one per rank).
+
+    Replaces what ``functionspace`` / ``dirichletbc`` / ``create_matrix`` /
+    ``fem.form`` build for the reference (:127-147, :45-46, :271-272).
+    """
+
+    def __init__(self, mesh: TetMesh, bcs, *, device="cuda:0", options: SnsOptions | None = None, **opt_kw):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FlowProblem needs a HIP device; the hot path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.mesh = mesh
+        if isinstance(bcs, DirichletSet):
+            mask, g = bcs.flatten()
+        else:
+            mask, g = bcs
+        self.bc_mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.bc_val = np.ascontiguousarray(g, dtype=np.float64)
+        self.options = options if options is not None else default_options(**opt_kw)
+        pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+        tets = np.ascontiguousarray(mesh.tets, dtype=np.int32)
+        if self.bc_mask.shape != (4 * len(pts),) or self.bc_val.shape != (4 * len(pts),):
+            raise ValueError("bc arrays must have 4*num_nodes entries")
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        check(self.lib.sns_create(C.byref(h), len(pts), len(tets), pts.ctypes.data, tets.ctypes.data,
+                                  self.bc_mask.ctypes.data, self.bc_val.ctypes.data, idx, C.byref(self.options)))
+        self.h = h
+        self.n_local = len(pts)
+        self.n_owned = len(pts)
+        with torch.cuda.device(self.device):
+            check(self.lib.sns_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self.g_dev = torch.from_numpy(self.bc_val).to(self.device)
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sns_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------
+    @property
+    def ndof(self) -> int:
+        return 4 * self.n_local
+
+    def zeros(self) -> torch.Tensor:
+        return torch.zeros(self.ndof, dtype=torch.float64, device=self.device)
+
+    def _vec(self, x) -> torch.Tensor:
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+        if x.dtype != torch.float64 or x.device.type != "cuda" or not x.is_contiguous() or x.numel() != self.ndof:
+            raise ValueError(f"expected a contiguous float64 device vector of {self.ndof} entries")
+        return x
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if k == "ksp_type" and isinstance(v, str):
+                v = _lib.KSP_NAMES[v]
+            if k == "pc_type" and isinstance(v, str):
+                v = _lib.PC_NAMES[v]
+            if not hasattr(self.options, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(self.options, k, v)
+        check(self.lib.sns_set_options(self.h, C.byref(self.options)))
+
+    # -- hot path -------------------------------------------------------------
+    def residual(self, w, form="ns", out=None) -> torch.Tensor:
+        """F(w) as the reference's .F callback leaves it (:51-67)."""
+        w = None if w is None else self._vec(w)
+        out = self.zeros() if out is None else self._vec(out)
+        check(self.lib.sns_residual(self.h, _FORMS[form], _ptr(w), _ptr(out)))
+        return out
+
+    def jacobian(self, w, form="ns", residual_out=None):
+        """Assemble J(w) into the handle (:69-75); optionally the fused residual."""
+        w = None if w is None else self._vec(w)
+        F = None if residual_out is None else self._vec(residual_out)
+        check(self.lib.sns_jacobian(self.h, _FORMS[form], _ptr(w), _ptr(F)))
+        return F
+
+    def spmv(self, x, out=None) -> torch.Tensor:
+        x = self._vec(x)
+        out = self.zeros() if out is None else self._vec(out)
+        check(self.lib.sns_spmv(self.h, _ptr(x), _ptr(out)))
+        return out
+
+    def pc_setup(self):
+        check(self.lib.sns_pc_setup(self.h))
+
+    def pc_apply(self, r, out=None) -> torch.Tensor:
+        r = self._vec(r)
+        out = self.zeros() if out is None else self._vec(out)
+        check(self.lib.sns_pc_apply(self.h, _ptr(r), _ptr(out)))
+        return out
+
+    def krylov_solve(self, b, x0=None):
+        b = self._vec(b)
+        x = self.zeros() if x0 is None else self._vec(x0).clone()
+        its, reason, rn = C.c_int(), C.c_int(), C.c_double()
+        check(self.lib.sns_krylov_solve(self.h, _ptr(b), _ptr(x), C.byref(its), C.byref(reason), C.byref(rn)))
+        return x, KrylovResult(its.value, reason.value, rn.value)
+
+    def stokes_solve(self):
+        U = self.zeros()
+        its, reason, rn = C.c_int(), C.c_int(), C.c_double()
+        check(self.lib.sns_stokes_solve(self.h, _ptr(U), C.byref(its), C.byref(reason), C.byref(rn)))
+        return U, KrylovResult(its.value, reason.value, rn.value)
+
+    def newton_solve(self, w):
+        w = self._vec(w)
+        its, reason, kits = C.c_int(), C.c_int(), C.c_int()
+        cap = self.options.snes_max_it + 2
+        hist = (C.c_double * cap)()
+        t0 = time.time()
+        check(self.lib.sns_newton_solve(self.h, _ptr(w), C.byref(its), C.byref(reason), C.byref(kits), hist, cap))
+        dt = time.time() - t0
+        return w, NewtonResult(its.value, reason.value, kits.value, list(hist[:its.value + 1]), dt)
+
+    # -- introspection ----------------------------------------------------------
+    def sizes(self):
+        nl, no, nt, nz = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        check(self.lib.sns_get_sizes(self.h, C.byref(nl), C.byref(no), C.byref(nt), C.byref(nz)))
+        return dict(n_local=nl.value, n_owned=no.value, n_tets=nt.value, nnzb=nz.value)
+
+    def export(self, what: int, dtype, count: int) -> torch.Tensor:
+        t = torch.empty(count, dtype=dtype, device=self.device)
+        check(self.lib.sns_export(self.h, what, _ptr(t), t.numel() * t.element_size()))
+        return t
+
+    def bsr(self):
+        """(rowptr, colind, vals[nnzb,4,4]) copies of the assembled operator."""
+        s = self.sizes()
+        rp = self.export(_lib.EXPORT_ROWPTR, torch.int32, s["n_local"] + 1)
+        ci = self.export(_lib.EXPORT_COLIND, torch.int32, s["nnzb"])
+        va = self.export(_lib.EXPORT_VALS, torch.float64, s["nnzb"] * 16)
+        return rp, ci, va.view(-1, 4, 4)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp, ci, va = self.bsr()
+        n = self.n_local
+        return sp.bsr_matrix((va.cpu().numpy(), ci.cpu().numpy(), rp.cpu().numpy()), shape=(4 * n, 4 * n)).tocsr()
+
+    def element_matrices(self) -> torch.Tensor:
+        """Ke [n_tets, a, b, c, d] of the last jacobian() call (element-kernel output)."""
+        s = self.sizes()
+        return self.export(_lib.EXPORT_KE, torch.float64, s["n_tets"] * 256).view(-1, 4, 4, 4, 4)
+
+    def timings(self) -> SnsTimings:
+        t = SnsTimings()
+        check(self.lib.sns_get_timings(self.h, C.byref(t)))
+        return t
+
+    def reset_timings(self):
+        check(self.lib.sns_reset_timings(self.h))
+
+    def bench_spmv(self, reps=20) -> float:
+        x = torch.randn(self.ndof, dtype=torch.float64, device=self.device)
+        y = self.zeros()
+        ms = C.c_double()
+        check(self.lib.sns_bench_spmv(self.h, _ptr(x), _ptr(y), reps, C.byref(ms)))
+        return ms.value
+
+    def bench_assemble(self, w, form="ns", reps=5) -> float:
+        w = self._vec(w)
+        F = self.zeros()
+        ms = C.c_double()
+        check(self.lib.sns_bench_assemble(self.h, _FORMS[form], _ptr(w), _ptr(F), reps, C.byref(ms)))
+        return ms.value
+
+
+class NonlinearPDE_SNESProblem:
+    """Drop-in for the reference class of the same name (:40-75): ``F(x, F)``
+    assembles the residual, ``J(x)`` the Jacobian, both on device vectors.
+    (The reference's first positional ``snes`` argument has no counterpart.)"""
+
+    def __init__(self, problem: FlowProblem, u: torch.Tensor):
+        self.problem = problem
+        self.u = u
+
+    def F(self, snes, x, F):
+        self.u.copy_(x)
+        self.problem.residual(x, "ns", out=F)
+
+    def J(self, snes, x, J=None, P=None):
+        self.problem.jacobian(x, "ns")
+
+
+def solve_stokes_problem(problem: FlowProblem, rank: int = 0):
+    """``solve_stokes_problem(a, L, bcs, W)`` of the reference (:197-218): returns U."""
+    if rank == 0:
+        print("Starting Linear Solve", flush=True)
+    U, res = problem.stokes_solve()
+    if rank == 0:
+        print(f"Finished Linear Solve (its {res.its}, reason {res.reason}, |r| {res.rnorm:.3e})", flush=True)
+    return U
+
+
+def solve_navier_stokes(problem: FlowProblem, w: torch.Tensor, rank: int = 0):
+    """``solve_navier_stokes(a, w, dF, bcs, W, ksp_type, comm, rank)`` (:268-312).
+
+    ``w`` is updated in place (``snes.solve(None, w)`` :293); returns
+    ``(w, u, p)`` with u (n,3) and p (n,) the collapsed sub-functions (:310-312).
+    """
+    if rank == 0:
+        print("Running SNES solver", flush=True)
+        print("Start Nonlinear Solve", flush=True)
+    w, res = problem.newton_solve(w)
+    if rank == 0:
+        print(f"Num SNES iterations: {res.its}", flush=True)
+        print(f"SNES termination reason: {res.reason}", flush=True)
+        print(f"Navier-Stokes solve time: {res.seconds:.2f} sec", flush=True)
+        print("Finished Nonlinear Solve", flush=True)
+    problem.last_newton = res
+    W = w.view(-1, 4)
+    return w, W[:, :3].contiguous(), W[:, 3].contiguous()
