@@ -176,11 +176,29 @@ typedef struct {
 } sns_timings;
 int sns_get_timings(sns_handle h, sns_timings* t);
 int sns_reset_timings(sns_handle h);
+/* per-launch HIP-event timing of the level-0 k_spmv family inside solves
+ * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot)     */
+int sns_time_kernels(sns_handle h, int on);
+int sns_get_kernel_times(sns_handle h, double ms_total[4], int64_t calls[4]);
 /* raw kernel launchers for micro-benchmarks (bench.py roofline leg): run the
  * kernel `reps` times between two HIP events on the handle's stream and return
  * the average duration in ms.                                                  */
 int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
 int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
+
+/* ---- host-only symbolic utilities (no GPU needed; used by sns_create and by
+ *      the CPU test-suite) ------------------------------------------------------
+ * BSR sparsity pattern of the P1-P1 operator (what create_matrix derives from
+ * the dofmap, :272) and the slot -> element-block gather lists of the
+ * atomic-free assembly.  Call with NULL outputs to query sizes.               */
+int sns_host_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets_host,
+                     int64_t* nnzb_out,
+                     int32_t* rowptr_out /*n_nodes+1*/, int32_t* colind_out /*nnzb*/,
+                     int64_t* c_ptr_out /*nnzb+1*/, int32_t* c_idx_out /*16*n_tets*/);
+/* size-limited greedy aggregation of the first n_active nodes of a pattern;
+ * agg_out[n_nodes] gets the aggregate id (-1 for inactive nodes).             */
+int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind,
+                       int32_t n_active, int max_agg, int32_t* agg_out, int32_t* n_agg_out);
 
 #ifdef __cplusplus
 }

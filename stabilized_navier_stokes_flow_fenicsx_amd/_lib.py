@@ -79,8 +79,12 @@ _SIGNATURES = [
     ("sns_export", C.c_int, [_H, C.c_int, _P, C.c_int64]),
     ("sns_get_timings", C.c_int, [_H, C.POINTER(SnsTimings)]),
     ("sns_reset_timings", C.c_int, [_H]),
+    ("sns_time_kernels", C.c_int, [_H, C.c_int]),
+    ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("sns_bench_spmv", C.c_int, [_H, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     ("sns_bench_assemble", C.c_int, [_H, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_double)]),
+    ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
+    ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -121,3 +125,32 @@ def default_options(**kw) -> SnsOptions:
             raise TypeError(f"unknown option {k}")
         setattr(o, k, v)
     return o
+
+
+def host_pattern(n_nodes: int, tets):
+    """(rowptr, colind, c_ptr, c_idx) of the BSR pattern + gather lists (host only)."""
+    import numpy as np
+    lib = load()
+    tets = np.ascontiguousarray(tets, dtype=np.int32)
+    nnzb = C.c_int64()
+    check(lib.sns_host_pattern(n_nodes, len(tets), tets.ctypes.data, C.byref(nnzb), None, None, None, None))
+    rowptr = np.empty(n_nodes + 1, np.int32)
+    colind = np.empty(nnzb.value, np.int32)
+    c_ptr = np.empty(nnzb.value + 1, np.int64)
+    c_idx = np.empty(16 * len(tets), np.int32)
+    check(lib.sns_host_pattern(n_nodes, len(tets), tets.ctypes.data, C.byref(nnzb), rowptr.ctypes.data,
+                               colind.ctypes.data, c_ptr.ctypes.data, c_idx.ctypes.data))
+    return rowptr, colind, c_ptr, c_idx
+
+
+def host_aggregate(rowptr, colind, n_active=None, max_agg=8):
+    import numpy as np
+    lib = load()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colind = np.ascontiguousarray(colind, dtype=np.int32)
+    n = len(rowptr) - 1
+    agg = np.empty(n, np.int32)
+    nc = C.c_int32()
+    check(lib.sns_host_aggregate(n, rowptr.ctypes.data, colind.ctypes.data, n if n_active is None else n_active,
+                                 max_agg, agg.ctypes.data, C.byref(nc)))
+    return agg, nc.value

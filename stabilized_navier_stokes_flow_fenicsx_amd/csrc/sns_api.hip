@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -110,6 +111,13 @@ struct sns_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<Comm> comm;
     std::unique_ptr<HostPattern> pattern;      // kept until the (lazy) hierarchy build
+    // optional per-launch timing of the fine-level SpMV family
+    bool time_kernels = false;
+    std::vector<std::array<hipEvent_t, 2>> ev_pool;
+    std::vector<int> ev_mode;
+    size_t ev_used = 0;
+    double kt_ms[4] = {0, 0, 0, 0};
+    int64_t kt_calls[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -121,6 +129,35 @@ inline int64_t nred_of(const sns_ctx* h) { return 4 * (int64_t)h->n_owned; }
 int sync_stream(sns_ctx* h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SNS_OK;
+}
+
+void time_begin(sns_ctx* h, int mode) {
+    if (!h->time_kernels) return;
+    if (h->ev_used == h->ev_pool.size()) {
+        std::array<hipEvent_t, 2> p;
+        (void)hipEventCreate(&p[0]);
+        (void)hipEventCreate(&p[1]);
+        h->ev_pool.push_back(p);
+        h->ev_mode.push_back(0);
+    }
+    h->ev_mode[h->ev_used] = mode;
+    (void)hipEventRecord(h->ev_pool[h->ev_used][0], h->stream);
+}
+void time_end(sns_ctx* h) {
+    if (!h->time_kernels) return;
+    (void)hipEventRecord(h->ev_pool[h->ev_used][1], h->stream);
+    ++h->ev_used;
+}
+// resolve recorded event pairs (stream must be idle)
+void time_collect(sns_ctx* h) {
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i][0], h->ev_pool[i][1]) == hipSuccess) {
+            h->kt_ms[h->ev_mode[i]] += ms;
+            h->kt_calls[h->ev_mode[i]]++;
+        }
+    }
+    h->ev_used = 0;
 }
 
 // finish a two-stage reduction: partial[nblocks][nred] -> dst_dev[0..nred) (+ all-reduce over ranks)
@@ -164,14 +201,29 @@ int halo_exchange(sns_ctx* h, double* x) {
     return SNS_OK;
 }
 
+// Per-launch timing of the level-0 SpMV family (bench.py roofline leg): event pairs are
+// recorded around every fine-level launch while h->time_kernels is set and resolved after
+// the solve has synchronised.
+struct EvPair { hipEvent_t a, b; int mode; };
+void time_begin(sns_ctx* h, int mode);
+void time_end(sns_ctx* h);
+
 // y = A_l x (or fused variants).  rows = number of block rows computed.
 template <int MODE>
 void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
                  double omega, const double* dotw) {
     const int grid = (rows + 31) / 32;
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_spmv<MODE>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y,
-                       b, L.dinv, omega, dotw, h->partial);
+    const bool fine = (&L == &h->levels[0]);
+    if (fine) {
+        time_begin(h, MODE);
+        hipLaunchKernelGGL((k_spmv<MODE, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
+                           x, y, b, L.dinv, omega, dotw, h->partial);
+        time_end(h);
+    } else if constexpr (MODE == SPMV_JACOBI || MODE == SPMV_B_MINUS_AX) {
+        hipLaunchKernelGGL((k_spmv<MODE, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
+                           x, y, b, L.dinv, omega, dotw, h->partial);
+    }
 }
 
 int alloc_level_vectors(Level& L) {
@@ -457,9 +509,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             {   // v = A ph, fused rhat.v
                 const int32_t rows = h->n_owned;
                 const int gs = (rows + 31) / 32;
-                hipLaunchKernelGGL((k_spmv<SPMV_AX_DOT>), dim3(gs), dim3(256), 0, h->stream, rows, h->levels[0].rowptr,
-                                   h->levels[0].colind, h->levels[0].vals, ph, v, nullptr, nullptr, 0.0, rhat,
-                                   h->partial);
+                launch_spmv<SPMV_AX_DOT>(h, h->levels[0], rows, ph, v, nullptr, 0.0, rhat);
                 h->tm.spmv_calls++;
                 SNS_TRY(reduce_to(h, gs, 1, h->d_scal));
             }
@@ -617,6 +667,7 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->tm.krylov_ms += ms;
     h->tm.ksp_its += *its;
+    time_collect(h);
     HIP_TRY(hipGetLastError());
     return SNS_OK;
 }
@@ -769,6 +820,7 @@ int sns_destroy(sns_handle h) {
     for (auto p : h->empty_c) fr(p);
     for (auto p : h->pong) fr(p);
     for (auto p : h->kv) fr(p);
+    for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
     fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -1047,6 +1099,17 @@ int sns_get_timings(sns_handle h, sns_timings* t) {
 int sns_reset_timings(sns_handle h) {
     if (!h) return SNS_E_ARG;
     h->tm = sns_timings{};
+    for (int i = 0; i < 4; ++i) { h->kt_ms[i] = 0; h->kt_calls[i] = 0; }
+    return SNS_OK;
+}
+int sns_time_kernels(sns_handle h, int on) {
+    if (!h) return SNS_E_ARG;
+    h->time_kernels = on != 0;
+    return SNS_OK;
+}
+int sns_get_kernel_times(sns_handle h, double ms_total[4], int64_t calls[4]) {
+    if (!h || !ms_total || !calls) return SNS_E_ARG;
+    for (int i = 0; i < 4; ++i) { ms_total[i] = h->kt_ms[i]; calls[i] = h->kt_calls[i]; }
     return SNS_OK;
 }
 

@@ -119,7 +119,7 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
 // neighbour joins the aggregate of its first aggregated neighbour.  Sequential
 // and therefore deterministic; O(nnzb).  Rows >= fine.n_owned ... are handled by
 // the caller through `owned` (nodes outside are never aggregated).
-static void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
+void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
                             int32_t& nc) {
     agg.assign((size_t)F.n, -1);
     nc = 0;
@@ -221,3 +221,42 @@ void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A)
 }
 
 }  // namespace sns
+
+// ---- host-only C ABI (include/sns.h) ------------------------------------------------
+extern "C" int sns_host_pattern(int32_t n, int64_t E, const int32_t* tets, int64_t* nnzb_out, int32_t* rowptr,
+                                int32_t* colind, int64_t* c_ptr, int32_t* c_idx) {
+    if (n <= 0 || E < 0 || !tets) { sns::set_error("sns_host_pattern: bad arguments"); return SNS_E_ARG; }
+    sns::HostPattern P;
+    sns::HostAssemblyMaps M;
+    try {
+        sns::build_pattern(n, E, tets, P, M);
+    } catch (const std::exception& e) {
+        sns::set_error(e.what());
+        return SNS_E_MESH;
+    }
+    if (nnzb_out) *nnzb_out = P.nnzb;
+    if (rowptr) std::copy(P.rowptr.begin(), P.rowptr.end(), rowptr);
+    if (colind) std::copy(P.colind.begin(), P.colind.end(), colind);
+    if (c_ptr) std::copy(M.c_ptr.begin(), M.c_ptr.end(), c_ptr);
+    if (c_idx) std::copy(M.c_idx.begin(), M.c_idx.end(), c_idx);
+    return SNS_OK;
+}
+
+extern "C" int sns_host_aggregate(int32_t n, const int32_t* rowptr, const int32_t* colind, int32_t n_active,
+                                  int max_agg, int32_t* agg_out, int32_t* n_agg_out) {
+    if (n <= 0 || !rowptr || !colind || !agg_out || n_active < 0 || n_active > n || max_agg < 1) {
+        sns::set_error("sns_host_aggregate: bad arguments");
+        return SNS_E_ARG;
+    }
+    sns::HostPattern F;
+    F.n = n;
+    F.rowptr.assign(rowptr, rowptr + n + 1);
+    F.nnzb = rowptr[n];
+    F.colind.assign(colind, colind + F.nnzb);
+    std::vector<int32_t> agg;
+    int32_t nc = 0;
+    sns::aggregate_nodes(F, n_active, max_agg, agg, nc);
+    std::copy(agg.begin(), agg.end(), agg_out);
+    if (n_agg_out) *n_agg_out = nc;
+    return SNS_OK;
+}

@@ -62,6 +62,7 @@ struct Level {
     double* dense_inv = nullptr;
 };
 
+void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc);
 void set_error(const std::string& s);
 
 }  // namespace sns

@@ -1,0 +1,262 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle and
+the committed golden vectors.  Tolerances (fp64 hot path):
+  element / global matrix / residual / SpMV : 1e-12 relative (round-off only)
+  Krylov-converged fields vs sparse LU      : 1e-6 relative velocity L2 (north_star)
+  Newton iteration histories                : same count, ||F|| equal to 1e-6 relative
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, rel
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+    return FlowProblem
+
+
+def _mesh_from(g):
+    from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M
+    return M.TetMesh(g["points"], g["tets"], np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+
+
+def test_native_library_is_loaded(gpu):
+    """The tests below run the in-tree HIP library, not a fallback."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    maps = open("/proc/self/maps").read()
+    _lib.load()
+    assert "libsns.so" in open("/proc/self/maps").read() or "libsns.so" in maps
+
+
+def test_element_kernel_against_golden_literal_forms(gpu):
+    """Each golden tet as a one-tet mesh: element Jacobian/residual vs the literal UFL restatement."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M
+    g = golden("element_ns.npz")
+    s = golden("element_stokes.npz")
+    for i in range(len(g["X"])):
+        m = M.TetMesh(g["X"][i].copy(), np.array([[0, 1, 2, 3]], np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
+        none = (np.zeros(16, np.uint8), np.zeros(16))
+        for corrected, Fk, Jk in ((0, "F", "J"), (1, "F_corrected", "J_corrected")):
+            P = gpu(m, none, reynolds=float(g["Re"][i]), corrected_convection=corrected, pc_type="bjacobi")
+            F = P.zeros()
+            P.jacobian(_dev(g["W"][i].reshape(16)), "ns", residual_out=F)
+            Ke = P.element_matrices().cpu().numpy()[0]            # [a,b,c,d]
+            assert rel(Ke.transpose(0, 2, 1, 3).reshape(16, 16), g[Jk][i]) < 1e-12
+            assert rel(F.cpu().numpy(), g[Fk][i]) < 1e-12
+            P.close()
+        P = gpu(m, none, pc_type="bjacobi")
+        P.jacobian(None, "stokes")
+        Ke = P.element_matrices().cpu().numpy()[0]
+        assert rel(Ke.transpose(0, 2, 1, 3).reshape(16, 16), s["A"][i]) < 1e-12
+        P.close()
+
+
+def test_golden_box_global_matrix_bitwise_reproducible(gpu):
+    import scipy.sparse as sp
+    g = golden("box_2x1x1.npz")
+    n = len(g["mask"])
+    P = gpu(_mesh_from(g), (g["mask"], g["g"]), reynolds=float(g["Re"]))
+    F = P.zeros()
+    P.jacobian(_dev(g["w"]), "ns", residual_out=F)
+    Jg = P.to_scipy()
+    Jo = sp.coo_matrix((g["J_val"], (g["J_row"], g["J_col"])), shape=(n, n)).tocsr()
+    assert abs(Jg - Jo).max() < 1e-12 * abs(Jo).max() and rel(F.cpu().numpy(), g["F"]) < 1e-12
+    v1 = P.bsr()[2].clone()
+    F2 = P.zeros()
+    P.jacobian(_dev(g["w"]), "ns", residual_out=F2)
+    assert torch.equal(v1, P.bsr()[2]) and torch.equal(F, F2)      # gather assembly: no atomics, fixed order
+    P.jacobian(None, "stokes")
+    Ao = sp.coo_matrix((g["A_val"], (g["A_row"], g["A_col"])), shape=(n, n)).tocsr()
+    assert abs(P.to_scipy() - Ao).max() < 1e-12 * abs(Ao).max()
+    P.close()
+
+
+@pytest.mark.parametrize("kind,Re", [("duct", 1.0), ("duct", 80.0), ("cavity", 30.0), ("channel", 10.0)])
+def test_assembly_spmv_residual_vs_oracle(gpu, kind, Re):
+    from oracle import assemble as asm
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    if kind == "duct":
+        m = M.duct_mesh((9, 5, 4), 3.0, jitter=0.2)
+        mask, g = B.duct_bcs(m).flatten()
+    elif kind == "cavity":
+        m = M.cavity_mesh(6, jitter=0.15)
+        mask, g = B.cavity_bcs(m).flatten()
+    else:
+        m = M.channel_mesh((8, 4, 4))
+        mask, g = B.channel_bcs(m, *B.two_stream_profiles(0.5)).flatten()
+    rng = np.random.default_rng(11)
+    w = rng.normal(size=m.num_dofs) * 0.4                       # does NOT satisfy the BCs: lifting is exercised
+    P = gpu(m, (mask, g), reynolds=Re)
+    F = P.zeros()
+    P.jacobian(_dev(w), "ns", residual_out=F)
+    Jo, Fo = asm.assemble_ns(m.points, m.tets, w, Re, mask, g)
+    assert abs(P.to_scipy() - Jo).max() < 1e-12 * abs(Jo).max()
+    assert rel(F.cpu().numpy(), Fo) < 1e-12
+    assert rel(P.residual(_dev(w), "ns").cpu().numpy(), Fo) < 1e-12
+    x = rng.normal(size=m.num_dofs)
+    assert rel(P.spmv(_dev(x)).cpu().numpy(), Jo @ x) < 1e-12
+    # Stokes operator + rhs through the linear residual at w = 0
+    Ao, bo = asm.assemble_stokes(m.points, m.tets, mask, g)
+    F0 = P.zeros()
+    P.jacobian(None, "stokes", residual_out=F0)
+    assert abs(P.to_scipy() - Ao).max() < 1e-12 * abs(Ao).max()
+    assert rel(-F0.cpu().numpy(), bo) < 1e-12
+    P.close()
+
+
+def test_block_jacobi_and_amg_are_linear_and_match_oracle_inverse(gpu):
+    from oracle import assemble as asm, solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((10, 4, 4), 3.0, jitter=0.1)
+    mask, g = B.duct_bcs(m).flatten()
+    P = gpu(m, (mask, g), reynolds=5.0, pc_type="bjacobi")
+    w = np.random.default_rng(2).normal(size=m.num_dofs) * 0.2
+    P.jacobian(_dev(w), "ns")
+    P.pc_setup()
+    Jo, _ = asm.assemble_ns(m.points, m.tets, w, 5.0, mask, g)
+    Dinv = S.block_jacobi_inverse(Jo)
+    r = np.random.default_rng(3).normal(size=m.num_dofs)
+    z = P.pc_apply(_dev(r)).cpu().numpy()
+    assert rel(z, np.einsum("nij,nj->ni", Dinv, r.reshape(-1, 4)).ravel()) < 1e-12
+    P.set_options(pc_type="amg")
+    P.pc_setup()
+    r2 = np.random.default_rng(4).normal(size=m.num_dofs)
+    za, zb = P.pc_apply(_dev(r)).cpu().numpy(), P.pc_apply(_dev(r2)).cpu().numpy()
+    zc = P.pc_apply(_dev(2.0 * r - 3.0 * r2)).cpu().numpy()
+    assert rel(zc, 2.0 * za - 3.0 * zb) < 1e-11                  # V-cycle is a fixed linear operator
+    # and a useful one: ||I - A M^-1|| applied to r reduces the residual
+    assert np.linalg.norm(r - Jo @ za) < 0.9 * np.linalg.norm(r)
+    P.close()
+
+
+@pytest.mark.parametrize("ksp,pc", [("fgmres", "amg"), ("bicgstab", "amg"), ("bicgstab", "bjacobi"), ("fgmres", "bjacobi")])
+def test_stokes_solve_vs_lu(gpu, ksp, pc):
+    from oracle import solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((12, 5, 5), 3.0)
+    mask, g = B.duct_bcs(m).flatten()
+    Uo, _ = S.solve_stokes(m.points, m.tets, mask, g)
+    P = gpu(m, (mask, g), ksp_type=ksp, pc_type=pc, ksp_rtol=1e-10, gmres_restart=60)
+    U, res = P.stokes_solve()
+    U = U.cpu().numpy()
+    assert res.reason > 0
+    assert rel(U.reshape(-1, 4)[:, :3], Uo.reshape(-1, 4)[:, :3]) < 1e-6        # north_star tolerance
+    assert rel(U, Uo) < 1e-6
+    assert np.allclose(U[mask.astype(bool)], g[mask.astype(bool)], atol=1e-9)
+    P.close()
+
+
+def test_bicgstab_iteration_history_matches_oracle(gpu):
+    """Same algorithm, same preconditioner => same iteration count as oracle.bicgstab_bj."""
+    from oracle import assemble as asm, solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((8, 4, 4), 2.0)
+    mask, g = B.duct_bcs(m).flatten()
+    A, b = asm.assemble_stokes(m.points, m.tets, mask, g)
+    xo, its_o, reason_o = S.bicgstab_bj(A, b, rtol=1e-8)
+    P = gpu(m, (mask, g), ksp_type="bicgstab", pc_type="bjacobi", ksp_rtol=1e-8)
+    U, res = P.stokes_solve()
+    assert res.reason == reason_o and abs(res.its - its_o) <= 2
+    assert rel(U.cpu().numpy(), xo) < 1e-6
+    P.close()
+
+
+def test_newton_history_matches_golden(gpu):
+    g = golden("duct_8x2x2.npz")
+    P = gpu(_mesh_from(g), (g["mask"], g["g"]), reynolds=float(g["Re"]))
+    w, res = P.newton_solve(_dev(g["U_stokes"]))
+    assert res.its == int(g["its"]) and res.reason == int(g["reason"])
+    assert np.allclose(res.fnorms[:-1], g["fnorms"][:-1], rtol=1e-6)
+    assert rel(w.cpu().numpy(), g["w_newton"]) < 1e-8
+    P.close()
+
+
+def test_newton_from_bc_violating_guess_uses_lifting(gpu):
+    from oracle import solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.cavity_mesh(5)
+    mask, g = B.cavity_bcs(m).flatten()
+    w0 = np.zeros(m.num_dofs)                                        # violates the lid BC
+    wo, info = S.newton(m.points, m.tets, w0, 20.0, mask, g)
+    P = gpu(m, (mask, g), reynolds=20.0)
+    w, res = P.newton_solve(_dev(w0))
+    assert res.its == info["its"] and res.reason == info["reason"]
+    assert rel(w.cpu().numpy().reshape(-1, 4)[:, :3], wo.reshape(-1, 4)[:, :3]) < 1e-6
+    P.close()
+
+
+def test_reference_driver_mirror(gpu, capsys):
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import solve_navier_stokes, solve_stokes_problem
+    m = M.duct_mesh((8, 3, 3), 2.0)
+    P = gpu(m, B.duct_bcs(m), reynolds=5.0)
+    U = solve_stokes_problem(P)
+    w, u, p = solve_navier_stokes(P, U.clone())
+    out = capsys.readouterr().out
+    assert "Num SNES iterations" in out and "SNES termination reason" in out and "Navier-Stokes solve time" in out
+    assert u.shape == (m.num_nodes, 3) and p.shape == (m.num_nodes,)
+    assert P.last_newton.reason > 0
+    P.close()
+
+
+def test_errors_fail_loudly(gpu):
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib, mesh as M
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.0]])       # coplanar: degenerate tet
+    m = M.TetMesh(pts, np.array([[0, 1, 2, 3]], np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
+    with pytest.raises(_lib.SnsError) as e:
+        gpu(m, (np.zeros(16, np.uint8), np.zeros(16)))
+    assert e.value.code == -4
+    m = M.duct_mesh((2, 2, 2), 1.0)
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B
+    P = gpu(m, B.duct_bcs(m))
+    with pytest.raises(_lib.SnsError) as e:
+        P.spmv(P.zeros())                                             # no matrix assembled yet
+    assert e.value.code == -3
+    with pytest.raises(ValueError):
+        P.spmv(torch.zeros(3, dtype=torch.float64, device="cuda"))
+    with pytest.raises(_lib.SnsError):
+        P.residual(None, "ns")                                        # NS needs a state
+    P.close()
+
+
+def test_full_size_properties_1M_tets(gpu):
+    """BASELINE-size checks through size-independent properties (oracle too slow here):
+    SpMV linearity, J(w) dw = dF/dw dw by central differences, Stokes solve residual,
+    agreement of the two Krylov methods."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((140, 35, 35), 4.0)                               # 1.03 M tets
+    P = gpu(m, B.duct_bcs(m), reynolds=100.0)
+    U, res = P.stokes_solve()
+    assert res.reason > 0
+    F0 = P.zeros()
+    P.jacobian(None, "stokes", residual_out=F0)
+    r = P.spmv(U) + F0                                                # A U - b, b = -F(0)
+    assert float(r.norm() / F0.norm()) < 1e-7
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(P.ndof, dtype=torch.float64, device="cuda", generator=gen)
+    y = torch.randn(P.ndof, dtype=torch.float64, device="cuda", generator=gen)
+    lin = P.spmv(2.5 * x - y) - (2.5 * P.spmv(x) - P.spmv(y))
+    assert float(lin.norm() / P.spmv(x).norm()) < 1e-13
+    # directional derivative of the NS residual vs J dw (BC dofs held fixed)
+    free = torch.from_numpy(1.0 - P.bc_mask.astype(np.float64)).cuda()
+    dw = x * free * 1e-2
+    P.jacobian(U, "ns")
+    Jdw = P.spmv(dw)
+    eps = 1e-4
+    fd = (P.residual(U + eps * dw, "ns") - P.residual(U - eps * dw, "ns")) / (2 * eps)
+    assert float(((Jdw - fd) * free).norm() / Jdw.norm()) < 1e-6
+    P.set_options(ksp_type="bicgstab")
+    U2, res2 = P.stokes_solve()
+    assert res2.reason > 0 and float((U2 - U).norm() / U.norm()) < 1e-5
+    P.close()

@@ -1,0 +1,158 @@
+"""Host logic and C-ABI surface (CPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+
+
+def test_box_mesh_counts_and_orientation():
+    m = M.duct_mesh((4, 3, 2), 4.0)
+    assert m.num_nodes == 5 * 4 * 3 and m.num_tets == 6 * 4 * 3 * 2
+    X = m.points[m.tets]
+    vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6
+    assert np.isclose(vol.sum(), 4.0) and vol.min() > 0
+    # boundary triangles: 2 per cell face on the box surface
+    assert len(m.facets) == 2 * 2 * (4 * 3 + 4 * 2 + 3 * 2)
+    t = m.meta["tags"]
+    assert len(m.find(t["inlet"])) == 2 * 3 * 2 and len(m.find(t["outlet"])) == 2 * 3 * 2
+    assert np.allclose(m.points[m.facet_nodes(t["inlet"]), 0], 0.0)
+    assert np.allclose(m.points[m.facet_nodes(t["outlet"]), 0], 4.0)
+
+
+def test_jitter_keeps_boundary_and_validity():
+    m0, m1 = M.duct_mesh((5, 4, 4), 2.0), M.duct_mesh((5, 4, 4), 2.0, jitter=0.2)
+    bnd = np.unique(m0.facets.ravel())
+    assert np.array_equal(m0.points[bnd], m1.points[bnd]) and not np.array_equal(m0.points, m1.points)
+    X = m1.points[m1.tets]
+    assert (np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) > 0).all()
+
+
+def test_msh_roundtrip_preserves_cell_local_order(tmp_path):
+    m = M.channel_mesh((3, 2, 2))
+    p = str(tmp_path / "c.msh")
+    M.write_msh2(m, p)
+    r = M.read_msh(p)
+    assert np.array_equal(r.tets, m.tets) and np.allclose(r.points, m.points)
+    assert sorted(map(tuple, np.sort(r.facets, 1))) == sorted(map(tuple, np.sort(m.facets, 1)))
+    assert set(r.facet_tags) == {1, 2, 3, 4}
+
+
+def test_msh41_reader(tmp_path):
+    txt = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$Entities
+0 0 1 1
+1 0 0 0 1 1 0 1 7 0
+1 0 0 0 1 1 1 1 9 0
+$EndEntities
+$Nodes
+1 4 1 4
+3 1 0 4
+1
+2
+3
+4
+0 0 0
+1 0 0
+0 1 0
+0 0 1
+$EndNodes
+$Elements
+2 2 1 2
+2 1 2 1
+1 1 2 3
+3 1 4 1
+2 2 1 3 4
+$EndElements
+"""
+    p = tmp_path / "t.msh"
+    p.write_text(txt)
+    r = M.read_msh(str(p))
+    assert r.num_tets == 1 and list(r.tets[0]) == [1, 0, 2, 3]          # file order kept
+    assert list(r.facet_tags) == [7] and list(r.facets[0]) == [0, 1, 2]
+
+
+def test_cavity_and_channel_bcs():
+    m = M.cavity_mesh(3)
+    mask, g = B.cavity_bcs(m).flatten()
+    lid = m.facet_nodes(m.meta["tags"]["lid"])
+    assert np.all(g[4 * lid] == 1.0) and np.all(g[4 * lid + 1] == 0.0)
+    assert mask[3] == 1 and mask.reshape(-1, 4)[:, 3].sum() == 1           # p pinned at the origin only
+    mc = M.channel_mesh((4, 4, 4))
+    p1, p2 = B.two_stream_profiles(0.5)
+    mk, gg = B.channel_bcs(mc, p1, p2).flatten()
+    inl = np.union1d(mc.facet_nodes(1), mc.facet_nodes(2))
+    assert np.all(gg[4 * inl + 1] == 0) and np.all(gg[4 * inl + 2] == 0) and gg[4 * inl].max() > 0
+
+
+def test_header_symbols_match_library(built_lib):
+    """Every function include/sns.h declares is exported by libsns.so and bound in _lib."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sns.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sns_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} not exported"
+    o = _lib.default_options()
+    assert o.ksp_rtol == 1e-8 and o.snes_max_it == 30 and o.snes_rtol == 1e-8     # reference's settings :281-283
+
+
+def test_host_pattern_matches_scipy(built_lib):
+    import scipy.sparse as sp
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    m = M.duct_mesh((5, 3, 4), 2.0)
+    rp, ci, cp, cx = _lib.host_pattern(m.num_nodes, m.tets)
+    rows = np.repeat(m.tets, 4, axis=1).ravel()
+    cols = np.tile(m.tets, (1, 4)).ravel()
+    A = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(m.num_nodes,) * 2).tocsr()
+    A.sort_indices()
+    assert np.array_equal(A.indptr, rp) and np.array_equal(A.indices, ci)
+    # gather lists: every element block appears exactly once, under the right slot, in tet order per slot
+    assert cp[-1] == 16 * m.num_tets and np.array_equal(np.sort(cx), np.arange(16 * m.num_tets))
+    slot_of = np.repeat(np.arange(len(ci)), np.diff(cp))
+    t, ab = cx // 16, cx % 16
+    a, b = ab // 4, ab % 4
+    row_of_slot = np.repeat(np.arange(m.num_nodes), np.diff(rp))
+    assert np.array_equal(row_of_slot[slot_of], m.tets[t, a]) and np.array_equal(ci[slot_of], m.tets[t, b])
+    assert A.data.sum() == cp[-1]
+    for s in (0, len(ci) // 2, len(ci) - 1):
+        assert np.all(np.diff(cx[cp[s]:cp[s + 1]] // 16) >= 0)
+
+
+def test_host_aggregation_covers_and_limits(built_lib):
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    m = M.duct_mesh((6, 4, 4), 2.0)
+    rp, ci, _, _ = _lib.host_pattern(m.num_nodes, m.tets)
+    agg, nc = _lib.host_aggregate(rp, ci, max_agg=8)
+    assert agg.min() == 0 and agg.max() == nc - 1 and nc < m.num_nodes / 3
+    # aggregates are connected to their seed: every member is the seed or its neighbour's aggregate
+    n_act = m.num_nodes - 10
+    agg2, nc2 = _lib.host_aggregate(rp, ci, n_active=n_act, max_agg=4)
+    assert np.all(agg2[n_act:] == -1) and agg2[:n_act].min() >= 0
+    agg3, nc3 = _lib.host_aggregate(rp, ci, max_agg=8)
+    assert np.array_equal(agg, agg3)                                           # deterministic
+
+
+def test_bad_mesh_is_rejected_on_host(built_lib):
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    with pytest.raises(_lib.SnsError):
+        _lib.host_pattern(4, np.array([[0, 1, 2, 7]], np.int32))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: the product package must not reference it."""
+    pkg = os.path.join(ROOT, "stabilized_navier_stokes_flow_fenicsx_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
