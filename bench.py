@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: Newton iterations of the stabilised P1-P1 Navier-Stokes solve
+on the 10.1 M-tet square duct (BASELINE.json configs[4], the configuration the metric
+is quoted on; it fits one MI355X), Re = 200.
+
+A "step" is ONE Newton iteration of a real Newton sequence started from the Stokes
+solution: fused Jacobian+residual assembly (HIP), AMG setup, FGMRES solve to rtol 1e-8
+(the reference's KSP tolerance, NavierStokesChannelFlow.py:283), bt line-search residual.
+When the sequence converges (||F|| < 1e-8, :281) it restarts from the Stokes solution.
+metric = M-DOF/s = N_dof / (t_assemble + t_solve) per Newton iteration / 1e6  (SURVEY 8d).
+
+  python bench.py [--gpus N --steps K --warmup W]           (N>1 under torch.distributed.run)
+N>1: the SAME mesh is element-partitioned over the ranks (strong scaling), halo exchange
+and dot-product all-reduces on RCCL inside libsns.so.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(sample_cells=(52, 13, 13), re_full=200.0, full_ny=75):
+    """Oracle ("port": numpy assembly + scipy sparse LU) timed on the host cores on a bounded
+    sample of the same workload: one Newton iteration on the ~52.7 k-tet duct (BASELINE
+    configs[0] size) at the same cell Reynolds number Re*h as the full run."""
+    from oracle import assemble as asm, solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh(sample_cells, 4.0)
+    mask, g = B.duct_bcs(m).flatten()
+    Re = re_full * sample_cells[1] / full_ny
+    U, _ = S.solve_stokes(m.points, m.tets, mask, g)
+    t0 = time.time()
+    J, F = asm.assemble_ns(m.points, m.tets, U, Re, mask, g)
+    t1 = time.time()
+    y = S.lu_solve(J, F)
+    t2 = time.time()
+    Fn = asm.residual_ns(m.points, m.tets, U - y, Re, mask, g)
+    t3 = time.time()
+    ndof = m.num_dofs
+    return {"value": ndof / (t3 - t0) / 1e6, "unit": "M-DOF/s", "cores": 1, "kind": "port",
+            "sample": f"1 Newton iteration (numpy assembly {t1 - t0:.2f}s + scipy splu {t2 - t1:.2f}s + residual "
+                      f"{t3 - t2:.2f}s) on duct {sample_cells} = {m.num_tets} tets / {ndof} dofs at Re={Re:.1f} "
+                      f"(same Re*h as the full run); ||F|| {np.linalg.norm(F):.2e} -> {np.linalg.norm(Fn):.2e}"}
+
+
+def pmc_traffic(kernel_substr="k_spmvILi2ELi1"):
+    """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc CSVs
+    (profiles/*pmc*counter_collection.csv), corrected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE is in KiB and reads half the bytes of a wide streaming read on gfx950 (x2);
+    WRITE_SIZE (KiB) is exact.  None if no such profile is committed."""
+    import csv
+    tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc*counter_collection.csv")):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") in tot:
+                    tot[row["Counter_Name"]][0] += float(row["Counter_Value"])
+                    tot[row["Counter_Name"]][1] += 1
+    if not (tot["FETCH_SIZE"][1] and tot["WRITE_SIZE"][1]):
+        return None
+    fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] * 1024.0 * 2.0
+    write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] * 1024.0
+    return fetch + write
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=str, default="300,75,75")
+    ap.add_argument("--re", type=float, default=200.0)
+    ap.add_argument("--ksp", type=str, default="fgmres")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    cells = tuple(int(c) for c in args.cells.split(","))
+    mesh = M.duct_mesh(cells, 4.0)
+    bcs = B.duct_bcs(mesh)
+    opts = dict(reynolds=args.re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
+    if world > 1:
+        P = FlowProblem.distributed(mesh, bcs, device=f"cuda:{local_rank}", **opts)
+    else:
+        P = FlowProblem(mesh, bcs, device=f"cuda:{local_rank}", **opts)
+    n_dof_global = mesh.num_dofs
+    U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
+    if sres.reason <= 0:
+        raise RuntimeError(f"Stokes solve did not converge: {sres}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    w = U.clone()
+    seq = 0
+    log = []
+
+    def step():
+        nonlocal w, seq
+        w, r = P.newton_solve(w)
+        seq += 1
+        log.append((r.fnorms[-1] if r.fnorms else float("nan"), r.ksp_its, r.reason))
+        if r.reason == 2 or r.reason == 3 or seq >= 30:       # sequence converged: start over
+            w = U.clone()
+            seq = 0
+        return r
+
+    for _ in range(args.warmup):
+        step()
+    P.reset_timings()
+    P.time_kernels(True)
+    log.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    P.time_kernels(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / max(1, args.steps) * 1e3
+    value = n_dof_global / (ms_per_step * 1e-3) / 1e6
+
+    tm = P.timings()
+    kt = P.kernel_times()
+    s = P.sizes()
+    # dominant kernel: the level-0 block-Jacobi sweep k_spmv<SPMV_JACOBI, FINE> (3 of the 5 fine-level
+    # matrix passes per FGMRES iteration).  Algorithmic bytes per launch:
+    #   132 B per nonzero block (128 values + 4 column index) + per block row 4 rowptr + 32 x + 32 b
+    #   + 128 Dinv + 32 y  = 132*nnzb + 228*n_rows
+    jac_ms, jac_calls = kt["jacobi"]
+    alg_bytes = 132.0 * s["nnzb"] + 228.0 * s["n_owned"]
+    roofline = None
+    if jac_calls > 0:
+        avg_ms = jac_ms / jac_calls
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                    "kernel": "k_spmv<SPMV_JACOBI,FINE>", "avg_launch_ms": round(avg_ms, 5),
+                    "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
+                    "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}
+                                        for k, v in kt.items() if v[1] > 0 and k != "jacobi"}}
+    out = {
+        "metric": "M-DOF/s (assembly+solve) per Newton iteration",
+        "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"duct {cells[0]}x{cells[1]}x{cells[2]} cells = {mesh.num_tets} tets, "
+                               f"{n_dof_global} dofs, Re={args.re:g}, Newton iteration (assemble J+F, AMG setup, "
+                               f"{args.ksp} rtol 1e-8, bt line search)",
+                   "parallelism": f"element-partitioned x{world}" if world > 1 else "single GPU",
+                   "newton_log_fnorm_kspits_reason": [(float(f"{a:.3e}"), b, c) for a, b, c in log],
+                   "phase_ms_per_step": {"assemble": round(tm.assemble_ms / args.steps, 3),
+                                         "pc_setup": round(tm.pc_setup_ms / args.steps, 3),
+                                         "krylov": round(tm.krylov_ms / args.steps, 3)},
+                   "amg_levels": tm.amg_levels, "stokes_its": sres.its},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(re_full=args.re, full_ny=cells[1])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    P.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

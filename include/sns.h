@@ -122,7 +122,9 @@ int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,
  * Neighbour k: we send the owned-node values listed in send_idx[send_ptr[k]..)
  * and receive into ghost slots recv_idx[recv_ptr[k]..) (local node ids).
  * nccl_unique_id: 128 bytes from sns_comm_unique_id on rank 0, broadcast by
- * the caller (torch.distributed).                                             */
+ * the caller (torch.distributed).  NULL = no communicator: the handle only
+ * learns its owned/ghost split and the caller moves ghost values itself
+ * (single-GPU tests of the partitioned path).                                  */
 int sns_comm_unique_id(char id_out[128]);
 int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_id[128],
                     int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,

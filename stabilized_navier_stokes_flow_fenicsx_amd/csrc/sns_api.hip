@@ -163,7 +163,7 @@ void time_collect(sns_ctx* h) {
 // finish a two-stage reduction: partial[nblocks][nred] -> dst_dev[0..nred) (+ all-reduce over ranks)
 int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
     hipLaunchKernelGGL(k_reduce_final, dim3(nred), dim3(256), 0, h->stream, nblocks, nred, h->partial, dst_dev);
-    if (h->comm && h->comm->nranks > 1)
+    if (h->comm && h->comm->comm)      // also with one rank: keeps the RCCL path exercised by 1-GPU tests
         NCCL_TRY(ncclAllReduce(dst_dev, dst_dev, nred, ncclDouble, ncclSum, h->comm->comm, h->stream));
     return SNS_OK;
 }
@@ -177,7 +177,7 @@ int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
 
 int halo_exchange(sns_ctx* h, double* x) {
     Comm* c = h->comm.get();
-    if (!c || c->nranks <= 1 || c->nbr.empty()) return SNS_OK;
+    if (!c || !c->comm || c->nranks <= 1 || c->nbr.empty()) return SNS_OK;
     const int nn = (int)c->nbr.size();
     const int32_t ns = c->send_ptr[nn], nr = c->recv_ptr[nn];
     if (ns > 0)
@@ -424,6 +424,14 @@ int pc_apply(sns_ctx* h, const double* r, double* z) {
                                h->levels[0].dinv, r, 1.0, z);
             return SNS_OK;
         case SNS_PC_AMG:
+            if (h->n > h->n_owned) {
+                // distributed: the per-rank V-cycle must see ZERO ghost values on level 0 (block-Jacobi across
+                // ranks, like PETSc's parallel default bjacobi).  z's ghost tail may hold halo data, so cycle
+                // in internal buffers whose tails are never written and copy the owned part out.
+                SNS_TRY(vcycle(h, 0, r, h->levels[0].x));
+                HIP_TRY(hipMemcpyAsync(z, h->levels[0].x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                return SNS_OK;
+            }
             return vcycle(h, 0, r, z);
     }
     set_error("bad pc_type");
@@ -661,6 +669,7 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
     else { set_error("bad ksp_type"); return SNS_E_ARG; }
     SNS_TRY(rc);
+    SNS_TRY(halo_exchange(h, x));                          // leave the solution's ghost tail current
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float ms = 0;
@@ -884,9 +893,11 @@ int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int
     Comm& c = *h->comm;
     c.rank = rank;
     c.nranks = nranks;
-    ncclUniqueId id;
-    std::memcpy(&id, uid, 128);
-    NCCL_TRY(ncclCommInitRank(&c.comm, nranks, id, rank));
+    if (uid) {
+        ncclUniqueId id;
+        std::memcpy(&id, uid, 128);
+        NCCL_TRY(ncclCommInitRank(&c.comm, nranks, id, rank));
+    }   // uid == NULL: local part only, the caller moves ghost values and reduces (tests)
     h->n_owned = n_owned;
     h->levels[0].n_owned = n_owned;
     c.nbr.assign(nbr, nbr + n_nbr);

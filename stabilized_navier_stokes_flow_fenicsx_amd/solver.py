@@ -56,7 +56,8 @@ class FlowProblem:
     ``fem.form`` build for the reference (:127-147, :45-46, :271-272).
     """
 
-    def __init__(self, mesh: TetMesh, bcs, *, device="cuda:0", options: SnsOptions | None = None, **opt_kw):
+    def __init__(self, mesh: TetMesh, bcs, *, device="cuda:0", options: SnsOptions | None = None, part=None,
+                 group=None, **opt_kw):
         if not torch.cuda.is_available():
             raise RuntimeError("FlowProblem needs a HIP device; the hot path has no CPU fallback")
         self.lib = _lib.load()
@@ -83,6 +84,67 @@ class FlowProblem:
         with torch.cuda.device(self.device):
             check(self.lib.sns_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         self.g_dev = torch.from_numpy(self.bc_val).to(self.device)
+        self.part = part
+        self.group = group
+        if part is not None:
+            self._attach_comm(part, group)
+
+    @classmethod
+    def distributed(cls, mesh: TetMesh, bcs, *, group=None, device=None, **kw):
+        """One rank's problem of an element-partitioned run (one process per GPU).
+
+        Every rank passes the same global mesh / BC data; RCB partition, local
+        renumbering and the halo plan are computed here (partition.py); the RCCL
+        communicator of the C-ABI is bootstrapped through torch.distributed."""
+        import torch.distributed as dist
+        from . import partition as PT
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        mask, g = bcs.flatten() if isinstance(bcs, DirichletSet) else bcs
+        owner = PT.rcb_partition(mesh.points, world)
+        part = PT.build_local_part(mesh, mask, g, owner, rank, world)
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}"
+        self = cls(part.mesh, (part.bc_mask, part.bc_val), device=device, part=part, group=group, **kw)
+        self.global_mesh = mesh
+        return self
+
+    def _attach_comm(self, part, group):
+        if group == "local-only":                      # tests: owned/ghost split without a communicator
+            box = [None]
+        else:
+            import torch.distributed as dist
+            uid = C.create_string_buffer(128)
+            if part.rank == 0:
+                check(self.lib.sns_comm_unique_id(uid))
+            box = [bytes(uid.raw)]
+            if part.nranks > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                           group=group)
+        nb = np.ascontiguousarray(part.neighbors, dtype=np.int32)
+        sp_, si = np.ascontiguousarray(part.send_ptr, np.int32), np.ascontiguousarray(part.send_idx, np.int32)
+        rp, ri = np.ascontiguousarray(part.recv_ptr, np.int32), np.ascontiguousarray(part.recv_idx, np.int32)
+        with torch.cuda.device(self.device):
+            check(self.lib.sns_attach_comm(self.h, part.rank, part.nranks, box[0], part.n_owned, len(nb),
+                                           nb.ctypes.data, sp_.ctypes.data, si.ctypes.data, rp.ctypes.data,
+                                           ri.ctypes.data))
+        self.n_owned = part.n_owned
+
+    def scatter(self, x_global) -> torch.Tensor:
+        """Local (owned + ghost) device copy of a global host dof vector."""
+        from . import partition as PT
+        xg = np.asarray(x_global, dtype=np.float64)
+        return torch.from_numpy(PT.scatter_global(self.part, xg) if self.part is not None else xg.copy()).to(self.device)
+
+    def gather(self, x_local) -> torch.Tensor:
+        """Global dof vector on every rank from the owned parts (setup / output only)."""
+        from . import partition as PT
+        if self.part is None or self.part.nranks == 1:
+            if self.part is None:
+                return x_local.clone()
+            out = torch.zeros(4 * len(self.part.l2g), dtype=x_local.dtype, device=x_local.device)
+            out.view(-1, 4)[torch.as_tensor(self.part.l2g, device=x_local.device)] = x_local.view(-1, 4)
+            return out
+        return PT.gather_owned(self.part, x_local, self.global_mesh.num_nodes, self.group)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
@@ -204,6 +266,17 @@ class FlowProblem:
         """Ke [n_tets, a, b, c, d] of the last jacobian() call (element-kernel output)."""
         s = self.sizes()
         return self.export(_lib.EXPORT_KE, torch.float64, s["n_tets"] * 256).view(-1, 4, 4, 4, 4)
+
+    def time_kernels(self, on=True):
+        check(self.lib.sns_time_kernels(self.h, 1 if on else 0))
+
+    def kernel_times(self):
+        """{mode: (total_ms, calls)} of the level-0 k_spmv family since reset_timings()."""
+        ms = (C.c_double * 4)()
+        calls = (C.c_int64 * 4)()
+        check(self.lib.sns_get_kernel_times(self.h, ms, calls))
+        names = ("ax", "b_minus_ax", "jacobi", "ax_dot")
+        return {names[i]: (ms[i], calls[i]) for i in range(4)}
 
     def timings(self) -> SnsTimings:
         t = SnsTimings()

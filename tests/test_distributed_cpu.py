@@ -1,0 +1,163 @@
+"""N>1 path on CPU: world_size-2/3 gloo runs of the partition + halo plan that the
+C-ABI consumes (sns_attach_comm), with the oracle doing the per-rank arithmetic.
+Checks: redundant ghost-tet assembly reproduces the owned rows exactly (no assembly
+communication needed), halo exchange + local SpMV == global SpMV, all-reduced dots,
+and a distributed block-Jacobi BiCGStab reaches the serial solution."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import assemble as asm, solve as S
+        if kind == "duct":
+            m = M.duct_mesh((8, 3, 3), 4.0, jitter=0.1)
+            mask, g = B.duct_bcs(m).flatten()
+        else:
+            m = M.cavity_mesh(5)
+            mask, g = B.cavity_bcs(m).flatten()
+        owner = PT.rcb_partition(m.points, world)
+        part = PT.build_local_part(m, mask, g, owner, rank, world)
+        rng = np.random.default_rng(42)
+        w = rng.normal(size=m.num_dofs) * 0.3
+        Re = 15.0
+        Jg, Fg = asm.assemble_ns(m.points, m.tets, w, Re, mask, g)
+        wl = PT.scatter_global(part, w)
+        Jl, Fl = asm.assemble_ns(part.mesh.points, part.mesh.tets, wl, Re, part.bc_mask, part.bc_val)
+        no = 4 * part.n_owned
+        gdof = (4 * part.l2g[:, None] + np.arange(4)[None]).ravel()
+        # owned rows of the redundantly assembled local operator == global rows
+        err_rows = abs(Jl[:no] - Jg[gdof[:no]][:, gdof]).max()
+        err_F = np.abs(Fl[:no] - Fg[gdof[:no]]).max()
+        # halo exchange + local SpMV
+        x = rng.normal(size=m.num_dofs)
+        xl = np.zeros(4 * part.n_local)
+        xl[:no] = x[gdof[:no]]
+        xt = torch.from_numpy(xl)
+        PT.halo_exchange_torch(part, xt)
+        err_halo = np.abs(xt.numpy() - x[gdof]).max()
+        yl = Jl[:no] @ xt.numpy()
+        err_spmv = np.abs(yl - (Jg @ x)[gdof[:no]]).max()
+        d = torch.tensor([float(xl[:no] @ xl[:no])], dtype=torch.float64)
+        dist.all_reduce(d)
+        err_dot = abs(float(d) - float(x @ x)) / float(x @ x)
+        # distributed block-Jacobi BiCGStab on the Stokes system
+        Ag, bg = asm.assemble_stokes(m.points, m.tets, mask, g)
+        Al, bl_full = asm.assemble_stokes(part.mesh.points, part.mesh.tets, part.bc_mask, part.bc_val)
+        Al = Al[:no]
+        bl = bg[gdof[:no]]
+        Dinv = S.block_jacobi_inverse(Ag)[part.l2g[: part.n_owned]]
+
+        def Mv(v):
+            return np.einsum("nij,nj->ni", Dinv, v.reshape(-1, 4)).ravel()
+
+        def Av(v):
+            t = torch.zeros(4 * part.n_local, dtype=torch.float64)
+            t[:no] = torch.from_numpy(v)
+            PT.halo_exchange_torch(part, t)
+            return Al @ t.numpy()
+
+        def gdot(a, b):
+            t = torch.tensor([float(a @ b)], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t)
+
+        xk = np.zeros(no)
+        r = bl - Av(xk)
+        rhat = r.copy()
+        rho = alpha = omega = 1.0
+        v = np.zeros(no)
+        p = np.zeros(no)
+        bn = np.sqrt(gdot(bl, bl))
+        its = 0
+        for its in range(1, 400):
+            rho_new = gdot(rhat, r)
+            beta = (rho_new / rho) * (alpha / omega)
+            p = r + beta * (p - omega * v)
+            ph = Mv(p)
+            v = Av(ph)
+            alpha = rho_new / gdot(rhat, v)
+            s = r - alpha * v
+            sh = Mv(s)
+            t = Av(sh)
+            omega = gdot(t, s) / gdot(t, t)
+            xk = xk + alpha * ph + omega * sh
+            r = s - omega * t
+            rho = rho_new
+            if np.sqrt(gdot(r, r)) <= 1e-10 * bn:
+                break
+        Ug = S.lu_solve(Ag, bg)
+        err_sol = np.abs(xk - Ug[gdof[:no]]).max() / np.abs(Ug).max()
+        xo, its_serial, _ = S.bicgstab_bj(Ag, bg, rtol=1e-10)
+        # gather_owned round trip
+        full = PT.gather_owned(part, torch.from_numpy(PT.scatter_global(part, w)), m.num_nodes)
+        err_gather = np.abs(full.numpy() - w).max()
+        q.put((rank, dict(err_rows=err_rows, err_F=err_F, err_halo=err_halo, err_spmv=err_spmv, err_dot=err_dot,
+                          err_sol=err_sol, its=its, its_serial=its_serial, err_gather=err_gather,
+                          n_owned=part.n_owned, n_local=part.n_local, nbr=list(map(int, part.neighbors)))))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, dict(error=traceback.format_exc())))
+
+
+@pytest.mark.parametrize("world,kind", [(2, "duct"), (3, "cavity")])
+def test_partition_halo_and_distributed_krylov_gloo(world, kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    tot_owned = 0
+    for r in range(world):
+        out = res[r]
+        assert "error" not in out, out.get("error")
+        assert out["err_rows"] < 1e-13 and out["err_F"] < 1e-13
+        assert out["err_halo"] == 0.0 and out["err_spmv"] < 1e-12 and out["err_dot"] < 1e-13
+        assert out["err_sol"] < 1e-6 and abs(out["its"] - out["its_serial"]) <= 3
+        assert out["err_gather"] == 0.0
+        assert out["n_local"] > out["n_owned"] and len(out["nbr"]) >= 1
+        tot_owned += out["n_owned"]
+    n_nodes = (9 * 4 * 4) if kind == "duct" else 6 ** 3
+    assert tot_owned == n_nodes                                   # every node owned exactly once
+
+
+def test_rcb_gives_x_slabs_on_the_duct():
+    m = M.duct_mesh((16, 3, 3), 4.0)
+    owner = PT.rcb_partition(m.points, 4)
+    assert np.bincount(owner).tolist() == [68, 68, 68, 68]
+    xmax = [m.points[owner == r, 0].max() for r in range(4)]
+    xmin = [m.points[owner == r, 0].min() for r in range(4)]
+    assert all(xmax[r] <= xmin[r + 1] + 1e-12 for r in range(3))   # slabs ordered in x
+    mask, g = B.duct_bcs(m).flatten()
+    parts = [PT.build_local_part(m, mask, g, owner, r, 4) for r in range(4)]
+    assert [len(p.neighbors) for p in parts] == [1, 2, 2, 1]       # <= 2 neighbours per GPU
+    for p in parts:                                                # send/recv plans are mutually consistent
+        for k, r in enumerate(p.neighbors):
+            q = parts[r]
+            kk = list(q.neighbors).index(p.rank)
+            sent = p.l2g[p.send_idx[p.send_ptr[k]:p.send_ptr[k + 1]]]
+            recv = q.l2g[q.recv_idx[q.recv_ptr[kk]:q.recv_ptr[kk + 1]]]
+            assert np.array_equal(sent, recv)
