@@ -1,0 +1,11 @@
+#!/usr/bin/env python
+"""Same command line as the reference's StokesChannelFlow.py; runs on the MI355X hot path
+(see stabilized_navier_stokes_flow_fenicsx_amd/drivers.py for what is kept and what differs)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from stabilized_navier_stokes_flow_fenicsx_amd.drivers import stokes_channel_main  # noqa: E402
+
+if __name__ == "__main__":
+    stokes_channel_main(sys.argv)

@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=str, default="300,75,75")
     ap.add_argument("--re", type=float, default=200.0)
-    ap.add_argument("--ksp", type=str, default="fgmres")
+    ap.add_argument("--ksp", type=str, default="bicgstab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

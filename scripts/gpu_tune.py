@@ -1,0 +1,28 @@
+"""Parameter sweep of the Krylov/AMG knobs: time-to-solution of the first Newton linear solve."""
+import sys, time, itertools
+import numpy as np, torch
+sys.path.insert(0, ".")
+from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
+from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+cells = eval(sys.argv[1]) if len(sys.argv) > 1 else (200, 50, 50)
+Re = 200.0 * cells[1] / 75.0
+m = M.duct_mesh(cells, 4.0)
+bcs = B.duct_bcs(m)
+base = None
+for agg in (8, 6, 12):
+    P = FlowProblem(m, bcs, reynolds=Re, amg_agg_size=agg)
+    U, res = P.stokes_solve()
+    F = P.zeros()
+    P.jacobian(U, "ns", residual_out=F)
+    for ksp, m_r, nu, om in [("fgmres", 30, 2, 0.8), ("fgmres", 60, 2, 0.8), ("fgmres", 30, 1, 0.7), ("fgmres", 30, 1, 0.8),
+                             ("fgmres", 30, 2, 0.7), ("fgmres", 30, 2, 0.9), ("fgmres", 30, 3, 0.8), ("bicgstab", 30, 2, 0.8),
+                             ("bicgstab", 30, 1, 0.8), ("fgmres", 100, 2, 0.8)]:
+        if agg != 8 and (ksp, m_r, nu, om) not in [("fgmres", 30, 2, 0.8), ("bicgstab", 30, 2, 0.8), ("fgmres", 30, 1, 0.8)]:
+            continue
+        P.set_options(ksp_type=ksp, gmres_restart=m_r, amg_nu=nu, amg_omega=om)
+        P.pc_setup()
+        P.reset_timings()
+        y, r = P.krylov_solve(F)
+        t = P.timings()
+        print(f"agg {agg:2d} {ksp:8s} m {m_r:3d} nu {nu} om {om}: its {r.its:4d} reason {r.reason} krylov {t.krylov_ms:8.1f} ms levels {t.amg_levels}", flush=True)
+    P.close()

@@ -160,12 +160,19 @@ void time_collect(sns_ctx* h) {
     h->ev_used = 0;
 }
 
-// finish a two-stage reduction: partial[nblocks][nred] -> dst_dev[0..nred) (+ all-reduce over ranks)
-int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
+// finish a two-stage reduction locally: partial[nblocks][nred] -> dst_dev[0..nred)
+void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
     hipLaunchKernelGGL(k_reduce_final, dim3(nred), dim3(256), 0, h->stream, nblocks, nred, h->partial, dst_dev);
+}
+// sum `count` device doubles over the ranks (no-op without a communicator)
+int allreduce(sns_ctx* h, double* buf_dev, int count) {
     if (h->comm && h->comm->comm)      // also with one rank: keeps the RCCL path exercised by 1-GPU tests
-        NCCL_TRY(ncclAllReduce(dst_dev, dst_dev, nred, ncclDouble, ncclSum, h->comm->comm, h->stream));
+        NCCL_TRY(ncclAllReduce(buf_dev, buf_dev, count, ncclDouble, ncclSum, h->comm->comm, h->stream));
     return SNS_OK;
+}
+int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
+    reduce_local(h, nblocks, nred, dst_dev);
+    return allreduce(h, dst_dev, nred);
 }
 // ... and bring `count` doubles starting at src_dev to the host (synchronises the stream)
 int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
@@ -220,7 +227,7 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
         hipLaunchKernelGGL((k_spmv<MODE, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
                            x, y, b, L.dinv, omega, dotw, h->partial);
         time_end(h);
-    } else if constexpr (MODE == SPMV_JACOBI || MODE == SPMV_B_MINUS_AX) {
+    } else if constexpr (MODE != SPMV_AX_DOT) {
         hipLaunchKernelGGL((k_spmv<MODE, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
                            x, y, b, L.dinv, omega, dotw, h->partial);
     }
@@ -255,6 +262,12 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     const sns_options& o = h->opt;
     HostPattern cur = fine;
     int32_t n_active = h->n_owned;
+    // levels/side arrays must not reallocate while references into them are alive
+    const size_t cap = (size_t)std::max(2, o.amg_max_levels) + 2;
+    h->levels.reserve(cap);
+    h->slot_row.reserve(cap);
+    h->empty_c.reserve(cap);
+    h->pong.reserve(cap);
     for (int l = 0; l + 1 < o.amg_max_levels; ++l) {
         if (n_active <= o.amg_coarse_size) break;
         HostAggregation A;
@@ -272,6 +285,8 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         h->empty_c.push_back(nullptr);
         h->pong.push_back(nullptr);
         Level& C = h->levels.back();
+        Level& L0 = h->levels[l];                              // re-fetch (emplace_back may have moved storage)
+        if (&L0 != &L) { set_error("internal: level storage moved"); return SNS_E_STATE; }
         SNS_TRY(upload_pattern(C, A.coarse, &h->slot_row.back(), h->stream));
         C.n_owned = C.n;
         SNS_TRY(alloc_level_vectors(C));
@@ -333,6 +348,39 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
 }
 
 // ---- preconditioner -----------------------------------------------------------
+// |lambda|max of Dinv*A on level l by a few power iterations (device resident; one host sync).
+// The damped block-Jacobi smoother x += w Dinv (b - A x) needs w*|lambda|max < 2; on the reference's
+// operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at 1.5/|lambda|max (smoothing-optimal damping is ~4/(3 lambda_max)).
+int estimate_lambda_max(sns_ctx* h, int l, double* out) {
+    Level& L = h->levels[l];
+    const int32_t rows = (l == 0) ? h->n_owned : L.n;
+    const int64_t nd = 4 * (int64_t)rows;
+    const int g = vec_grid(nd), g4 = (int)((nd + 255) / 256);
+    double* x = h->pong[l];
+    double* y = L.r;
+    double* z = L.x;
+    // deterministic start vector with all frequencies: x_i = 1 + (i*2654435761 mod 1024)/1024 via axpby on an iota is
+    // overkill; use b of the last solve if any, else the diagonal-inverse row sums: simplest robust choice = all ones
+    hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, x);
+    double lam = 0.0;
+    const int iters = 8;
+    for (int it = 0; it < iters; ++it) {
+        launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
+        hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
+        hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, z, h->partial);   // (x.z, z.z)
+        reduce_local(h, g, 2, h->d_scal + 16 + 2 * it);
+        // normalise with the device-side norm: x = z / ||z||  (scale read on device)
+        hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, h->d_scal + 16 + 2 * it + 1, z, x);
+    }
+    std::vector<double> v(2 * iters);
+    SNS_TRY(fetch(h, h->d_scal + 16, 2 * iters, v.data()));
+    // x was normalised each step, so ||z|| of the last steps estimates |lambda|max; take the max of the tail
+    for (int it = iters - 3; it < iters; ++it) lam = std::max(lam, std::sqrt(v[2 * it + 1]));
+    *out = lam;
+    // scratch vectors must be left zero in their ghost tails / unused parts: they were only written on [0, nd)
+    return SNS_OK;
+}
+
 int pc_setup(sns_ctx* h) {
     if (!h->has_matrix) { set_error("pc_setup before a matrix was assembled"); return SNS_E_STATE; }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -341,6 +389,14 @@ int pc_setup(sns_ctx* h) {
         Level& L = h->levels[l];
         const int32_t rows = (l == 0) ? h->n_owned : L.n;
         hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
+        L.omega = h->opt.amg_omega;
+        if (h->opt.pc_type == SNS_PC_AMG && !(L.dense_inv && l + 1 == nl)) {
+            double lam = 0.0;
+            SNS_TRY(estimate_lambda_max(h, l, &lam));
+            L.lambda_max = lam;
+            if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, 1.5 / lam);
+            if (h->opt.monitor) std::printf("    AMG level %d: n %d |lambda|max(Dinv A) %.4f omega %.4f\n", l, rows, lam, L.omega);
+        }
         if (l + 1 < nl) {
             Level& C = h->levels[l + 1];
             const int64_t nth = C.nnzb * 16;
@@ -372,7 +428,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     Level& L = h->levels[l];
     const int32_t rows = (l == 0) ? h->n_owned : L.n;
     const bool last = (l + 1 == (int)h->levels.size());
-    const double om = h->opt.amg_omega;
+    const double om = L.omega;
     const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
     if (last) {
         if (L.dense_inv) {
@@ -572,7 +628,6 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
     double* Z = h->gm_Z;
     double* dh1 = h->d_h;                 // pass-1 coefficients [m+8]
     double* dh2 = h->d_h + (m + 8);       // pass-2 coefficients, then ||w||^2 at [m+8 - 1 .. ]
-    double* dnrm = h->d_h + 2 * (m + 8);
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1), y(m), hcol(2 * (m + 8) + 1);
     double bnorm, rn;
     SNS_TRY(norm2(h, b, &bnorm));
@@ -598,27 +653,42 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
             SNS_TRY(pc_apply(h, vj, zj));
             SNS_TRY(op_apply(h, zj, w));
             const int nv = j + 1;
+            // CGS2 with TWO global reductions per iteration: pass 1 dots; pass 2 dots + (w.w), the new
+            // norm follows from ||w - V h2||^2 = w.w - |h2|^2 (V orthonormal).
             for (int pass = 0; pass < 2; ++pass) {
                 double* dh = pass == 0 ? dh1 : dh2;
                 for (int c0 = 0; c0 < nv; c0 += 8) {
                     const int cn = std::min(8, nv - c0);
                     hipLaunchKernelGGL(k_multi_dot8, dim3(g), dim3(256), 0, h->stream, nd, cn, V + (size_t)c0 * ld, ld,
                                        w, h->partial);
-                    SNS_TRY(reduce_to(h, g, 8, dh + c0));
+                    reduce_local(h, g, 8, dh + c0);
+                }
+                if (pass == 1) {
+                    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, w, w, h->partial);
+                    reduce_local(h, g, 1, dh + (m + 7));          // last slot of the pass-2 block: w.w
+                    SNS_TRY(allreduce(h, dh, m + 8));
+                } else {
+                    SNS_TRY(allreduce(h, dh, nv));
                 }
                 for (int c0 = 0; c0 < nv; c0 += 8) {
                     const int cn = std::min(8, nv - c0);
-                    const bool lastc = (pass == 1) && (c0 + 8 >= nv);
                     hipLaunchKernelGGL(k_multi_axpy8, dim3(g), dim3(256), 0, h->stream, nd, cn, V + (size_t)c0 * ld,
-                                       ld, dh + c0, -1.0, w, lastc ? h->partial : (double*)nullptr);
-                    if (lastc) SNS_TRY(reduce_to(h, g, 1, dnrm));
+                                       ld, dh + c0, -1.0, w, (double*)nullptr);
                 }
             }
-            // one device->host transfer per iteration: h1[0..nv), h2[0..nv), ||w||^2
-            SNS_TRY(fetch(h, h->d_h, 2 * (m + 8) + 1, hcol.data()));
+            // one device->host transfer per iteration: h1[0..nv), h2[0..nv), w.w
+            SNS_TRY(fetch(h, h->d_h, 2 * (m + 8), hcol.data()));
             double* Hj = &H[(size_t)j * (m + 1)];             // column j
-            for (int k = 0; k < nv; ++k) Hj[k] = hcol[k] + hcol[(m + 8) + k];
-            const double wn = std::sqrt(std::max(0.0, hcol[2 * (m + 8)]));
+            double h2sq = 0.0;
+            for (int k = 0; k < nv; ++k) {
+                Hj[k] = hcol[k] + hcol[(m + 8) + k];
+                h2sq += hcol[(m + 8) + k] * hcol[(m + 8) + k];
+            }
+            const double ww = hcol[(m + 8) + (m + 7)];
+            double wn2 = ww - h2sq;
+            double wn;
+            if (!(wn2 > 1e-6 * ww)) SNS_TRY(norm2(h, w, &wn));   // heavy cancellation: measure it
+            else wn = std::sqrt(wn2);
             Hj[nv] = wn;
             if (wn > 0.0) hipLaunchKernelGGL(k_scale_copy, dim3(g), dim3(256), 0, h->stream, nd, 1.0 / wn, w, w);
             for (int k = 0; k < j; ++k) {                      // previous rotations
@@ -701,7 +771,7 @@ extern "C" {
 
 void sns_default_options(sns_options* o) {
     o->reynolds = 1.0;
-    o->ksp_type = SNS_KSP_FGMRES;
+    o->ksp_type = SNS_KSP_BICGSTAB;
     o->pc_type = SNS_PC_AMG;
     o->ksp_rtol = 1e-8;
     o->ksp_atol = 1e-50;
@@ -771,6 +841,10 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
     SNS_TRY(dev_upload(&h->nt_idx, M.nt_idx, nullptr));
     SNS_TRY(dev_upload(&h->c_ptr, M.c_ptr, nullptr));
     SNS_TRY(dev_upload(&h->c_idx, M.c_idx, nullptr));
+    h->levels.reserve(64);
+    h->slot_row.reserve(64);
+    h->empty_c.reserve(64);
+    h->pong.reserve(64);
     h->levels.emplace_back();
     h->slot_row.push_back(nullptr);
     h->empty_c.push_back(nullptr);

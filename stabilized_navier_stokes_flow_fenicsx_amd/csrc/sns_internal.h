@@ -60,6 +60,9 @@ struct Level {
     double *x = nullptr, *b = nullptr, *r = nullptr;
     // coarsest level: dense inverse (4n x 4n), row-major
     double* dense_inv = nullptr;
+    // block-Jacobi damping actually used on this level (<= amg_omega, limited by 1.5/|lambda|max(Dinv A))
+    double omega = 0.8;
+    double lambda_max = 0.0;
 };
 
 void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc);

@@ -55,6 +55,8 @@ __global__ void k_dense_inverse(int N, double* A, int* piv, int* singular);
 __global__ void k_dense_matvec(int N, const double* D, const double* x, double* y);
 __global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
 __global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
+__global__ void k_fill_pattern(int64_t n, double* x);
+__global__ void k_scale_by_rsqrt(int64_t n, const double* s2, const double* x, double* y);
 __global__ void k_fill_slot_row(int32_t n, const int32_t* rowptr, int32_t* slot_row);
 
 }  // namespace sns

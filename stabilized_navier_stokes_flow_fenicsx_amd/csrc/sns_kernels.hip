@@ -207,6 +207,11 @@ __global__ __launch_bounds__(EL_TPB) void k_element(int64_t n_tets, const int32_
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0;
     double Rl[4] = {0.0, 0.0, 0.0, 0.0};                 // residual of local node a (lanes with b==0 only, NS)
+    // Jacobian blocks are needed when they are stored, or when this tet has a Dirichlet dof whose
+    // value differs from g (lifting term A0[:,B](g - x_B), :65).  Residual-only evaluations of the
+    // line search skip them otherwise.
+    const unsigned long long lift_mask = __ballot(live && S.GW[l] != 0.0);
+    const bool need_blocks = store_K || FORM == SNS_FORM_STOKES || ((lift_mask >> (threadIdx.x & 48)) & 0xFFFFull) != 0;
     if (live) {
         const double ga0 = S.g[3 * a], ga1 = S.g[3 * a + 1], ga2 = S.g[3 * a + 2];
         const double gb0 = S.g[3 * b], gb1 = S.g[3 * b + 1], gb2 = S.g[3 * b + 2];
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(EL_TPB) void k_element(int64_t n_tets, const int32_
                         cu[j] = dtau;                                              // used differently below
                     }
                 }
-                if (!corrected) {
+                if (!need_blocks) {
+                } else if (!corrected) {
                     const double A1 = pa * ugb + nu * gab + tau * sa * pb;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -511,6 +517,7 @@ SNS_INST_SPMV(SPMV_AX, 1)
 SNS_INST_SPMV(SPMV_B_MINUS_AX, 1)
 SNS_INST_SPMV(SPMV_JACOBI, 1)
 SNS_INST_SPMV(SPMV_AX_DOT, 1)
+SNS_INST_SPMV(SPMV_AX, 0)
 SNS_INST_SPMV(SPMV_B_MINUS_AX, 0)
 SNS_INST_SPMV(SPMV_JACOBI, 0)
 
@@ -923,6 +930,22 @@ __global__ __launch_bounds__(256) void k_unpack(int32_t m, const int32_t* __rest
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 4 * (int64_t)m) return;
     x[4 * (int64_t)idx[gid >> 2] + (gid & 3)] = buf[gid];
+}
+
+// deterministic rough start vector for the power iteration (all ones plus a cheap hash ripple)
+__global__ __launch_bounds__(256) void k_fill_pattern(int64_t n, double* __restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned hsh = (unsigned)(i * 2654435761u) >> 22;          // 10 bits
+        x[i] = 1.0 + ((double)hsh - 512.0) * (1.0 / 1024.0);
+    }
+}
+// y = x / sqrt(*s2)   (s2 = squared norm on the device; avoids a host round trip per power iteration)
+__global__ __launch_bounds__(256) void k_scale_by_rsqrt(int64_t n, const double* __restrict__ s2,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+    const double s = *s2;
+    const double a = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i];
 }
 
 __global__ __launch_bounds__(256) void k_fill_slot_row(int32_t n, const int32_t* __restrict__ rowptr,

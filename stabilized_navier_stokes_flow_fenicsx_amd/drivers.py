@@ -1,0 +1,290 @@
+"""Entry points with the reference's command lines, on the HIP hot path.
+
+  NavierStokesChannelFlow.py <Re> <img_fname> <flowrate_ratio> [<channel_mesh_size>=0.1]
+        (NavierStokes/NavierStokesChannelFlow.py:81-93, flow :468-580)
+  StokesChannelFlow.py       <img_fname> <flowrate_ratio> [<mesh_size>=0.25]
+        (StokesFlow/StokesChannelFlow.py:34-41)
+  DuctStokesFlow.py          <gmsh_fname> <mesh_lc> <x_outlet>
+        (StokesFlow/DuctStokesFlow.py:18-20)
+  LidDrivenNavierStokesFlow.py <Re> [<NumCells>=64]
+        (LidDrivenFlow/LidDrivenNavierStokesFlow.py:17-23)
+
+What is kept: argv, the Stokes -> coarse NS -> fine NS continuation (:513-530),
+boundary-condition sets, solver settings, printed diagnostics, output folder /
+file names.  What differs, because gmsh / skimage / dolfinx do not exist offline
+(SURVEY 8f, next-row 2): ``<img_fname>`` may be a gmsh ``.msh`` file (tags
+inlet_1=1, inlet_2=2, outlet=3, wall=4), otherwise the 4x1x1 channel is meshed by
+the built-in box mesher with a centred square inner stream and analytic inlet
+profiles normalised exactly like image2inlet.py:323-339.  DuctStokesFlow keeps
+the geometry/BCs/CLI of the reference file but solves the P1-P1 stabilised form
+(the north-star discretisation), not its P2-P1 + MUMPS one.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import bcs as B, mesh as M
+from .interpolate import interpolate_initial_guess
+
+snes_ksp_type = "bicgstab"          # reference: 'tfqmr' (:77); both are short-recurrence Lanczos-type methods
+
+
+def _rank():
+    try:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_initialized() else 0
+    except Exception:
+        return 0
+
+
+# --------------------------------------------------------------------------- #
+# argv
+# --------------------------------------------------------------------------- #
+def parse_arguments(argv=None):
+    """Same contract and error as the reference (:81-93)."""
+    argv = sys.argv if argv is None else argv
+    if len(argv) not in [4, 5]:
+        raise ValueError("Usage: script.py <Re> <img_fname> <flowrate_ratio> [<channel_mesh_size>]")
+    Re = int(argv[1])
+    img_fname = argv[2]
+    if hasattr(img_fname, "removeprefix"):
+        img_fname = img_fname.removeprefix(".")
+    elif img_fname.startswith("."):
+        img_fname = img_fname[1:]
+    img_fname = os.getcwd() + img_fname if not os.path.isabs(img_fname) else img_fname
+    flowrate_ratio = float(argv[3])
+    channel_mesh_size = float(argv[4]) if len(argv) == 5 else 0.1
+    return Re, img_fname, flowrate_ratio, channel_mesh_size
+
+
+def lc_to_cells(lc: float, length: float = 4.0):
+    """Structured stand-in for gmsh's characteristic length: h = lc on a length x 1 x 1 box."""
+    n = max(2, int(round(1.0 / lc)))
+    return (max(2, int(round(length / lc))), n, n)
+
+
+# --------------------------------------------------------------------------- #
+# mesh + BCs  (generate_mesh :107-116, create_boundary_conditions :127-147)
+# --------------------------------------------------------------------------- #
+def generate_mesh(img_fname: str, channel_mesh_size: float):
+    if _rank() == 0:
+        print("Meshing", flush=True)
+    if img_fname.endswith(".msh") and os.path.exists(img_fname):
+        msh = M.read_msh(img_fname)
+        msh.meta.update(kind="channel", tags=dict(M.CHANNEL_TAGS))
+    else:
+        msh = M.channel_mesh(lc_to_cells(channel_mesh_size))
+    if _rank() == 0:
+        print(f"Num elem: {msh.num_tets}", flush=True)
+    return msh
+
+
+def create_boundary_conditions(msh, flowrate_ratio):
+    p1, p2 = B.two_stream_profiles(flowrate_ratio, msh.meta.get("inner_half_width", 0.25))
+    return B.channel_bcs(msh, p1, p2)
+
+
+# --------------------------------------------------------------------------- #
+# output (make_output_folder :416-465, write_run_metadata :384-413,
+#         save_navier_stokes_solution :316-346)
+# --------------------------------------------------------------------------- #
+def make_output_folder(Re, img_fname, channel_mesh_size):
+    cwd = os.getcwd()
+    img_name = img_fname[:-4] if img_fname.endswith((".png", ".msh")) else img_fname
+    if img_name.startswith(cwd):
+        img_name = img_name[len(cwd):]
+    if img_name.startswith("/InletImages/"):
+        img_name = img_name[len("/InletImages/"):]
+    img_name = img_name.strip("/").replace("/", "_")
+    mesh_str = str(channel_mesh_size).replace(".", "")
+    noether = os.path.join(cwd, "noether_data")
+    folder = os.path.join(noether, f"NSChannelFlow_RE{Re}_MeshLC{mesh_str}_{img_name}")
+    if _rank() == 0:
+        os.makedirs(folder, exist_ok=True)
+    return folder, img_name
+
+
+def write_run_metadata(folder, Re, img_fname, flowrate_ratio, channel_mesh_size, msh, nranks=1):
+    if _rank() != 0:
+        return
+    with open(os.path.join(folder, "RunParameters.txt"), "w") as fh:
+        fh.write(f"Re={Re}\n")
+        fh.write(f"img_filename={img_fname}\n")
+        fh.write(f"Flowrate Ratio={flowrate_ratio}\n")
+        fh.write(f"Channel Mesh Size={channel_mesh_size}\n")
+        fh.write(f"Pressure DOFs: {msh.num_nodes}\n")
+        fh.write(f"Velocity DOFs: {msh.num_nodes}\n")        # dolfinx counts blocked dofs: one per node
+        fh.write(f"{nranks} Cores Used\n")
+
+
+def write_xdmf(path_noext: str, msh, name: str, values: np.ndarray):
+    """P1 nodal field as XDMF + raw little-endian binaries (``write_mesh`` +
+    ``write_function`` of :333-341).  The reference stores heavy data in HDF5;
+    h5py is not available offline, so the heavy data are ``Format="Binary"`` items
+    -- same XDMF structure, same Grid/Attribute names (Velocity / Pressure)."""
+    base = os.path.basename(path_noext)
+    values = np.ascontiguousarray(values, dtype="<f8")
+    geo, topo, dat = path_noext + "_geometry.bin", path_noext + "_topology.bin", path_noext + f"_{name}.bin"
+    np.ascontiguousarray(msh.points, dtype="<f8").tofile(geo)
+    np.ascontiguousarray(msh.tets, dtype="<i4").tofile(topo)
+    values.tofile(dat)
+    ncomp = 1 if values.ndim == 1 else values.shape[1]
+    atype = "Scalar" if ncomp == 1 else "Vector"
+    dims = f"{msh.num_nodes} {ncomp}" if ncomp > 1 else f"{msh.num_nodes}"
+    xml = f"""<?xml version="1.0"?>
+<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>
+<Xdmf Version="3.0" xmlns:xi="https://www.w3.org/2001/XInclude">
+  <Domain>
+    <Grid Name="mesh" GridType="Uniform">
+      <Topology TopologyType="Tetrahedron" NumberOfElements="{msh.num_tets}" NodesPerElement="4">
+        <DataItem Dimensions="{msh.num_tets} 4" NumberType="Int" Precision="4" Format="Binary" Endian="Little">{base}_topology.bin</DataItem>
+      </Topology>
+      <Geometry GeometryType="XYZ">
+        <DataItem Dimensions="{msh.num_nodes} 3" NumberType="Float" Precision="8" Format="Binary" Endian="Little">{base}_geometry.bin</DataItem>
+      </Geometry>
+      <Attribute Name="{name}" AttributeType="{atype}" Center="Node">
+        <DataItem Dimensions="{dims}" NumberType="Float" Precision="8" Format="Binary" Endian="Little">{base}_{name}.bin</DataItem>
+      </Attribute>
+    </Grid>
+  </Domain>
+</Xdmf>
+"""
+    with open(path_noext + ".xdmf", "w") as fh:
+        fh.write(xml)
+
+
+def save_navier_stokes_solution(u, p, msh, FolderName, Re):
+    if _rank() != 0:
+        return
+    print("[Rank 0] Starting save_navier_stokes_solution()", flush=True)
+    write_xdmf(os.path.join(FolderName, f"Re{Re}ChannelPressure"), msh, "Pressure", np.asarray(p))
+    write_xdmf(os.path.join(FolderName, f"Re{Re}ChannelVelocity"), msh, "Velocity", np.asarray(u))
+    print("[Rank 0] Solution writing complete.", flush=True)
+
+
+# --------------------------------------------------------------------------- #
+# drivers
+# --------------------------------------------------------------------------- #
+def _problem(msh, bcs, **opt):
+    from .solver import FlowProblem
+    return FlowProblem(msh, bcs, **opt)
+
+
+def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
+    """The reference's three-stage continuation (:468-549): Stokes on the 0.1 mesh ->
+    Navier-Stokes on the 0.1 mesh -> Navier-Stokes on the user mesh, each stage
+    warm-started from the previous one."""
+    import torch
+    from .solver import solve_navier_stokes, solve_stokes_problem
+    Re, img_fname, flowrate_ratio, channel_mesh_size = parse_arguments(argv)
+    rank = _rank()
+    if rank == 0:
+        print("Accepted Inputs", flush=True)
+    # Solve Stokes Flow
+    msh = generate_mesh(img_fname, coarse_mesh_size)
+    bcs = create_boundary_conditions(msh, flowrate_ratio)
+    P = _problem(msh, bcs, reynolds=float(Re), ksp_type=snes_ksp_type, device=device)
+    U_stokes = solve_stokes_problem(P, rank)
+    # Solve Coarse Navier Stokes
+    if rank == 0:
+        print("Interpolating Stokes Flow", flush=True)
+    w_coarse, u, p = solve_navier_stokes(P, U_stokes.clone(), rank)
+    w_coarse_host = w_coarse.cpu().numpy()
+    P.close()
+    # Solve Navier Stokes With User Defined Mesh
+    msh_f = generate_mesh(img_fname, channel_mesh_size)
+    bcs_f = create_boundary_conditions(msh_f, flowrate_ratio)
+    Pf = _problem(msh_f, bcs_f, reynolds=float(Re), ksp_type=snes_ksp_type, device=device)
+    if rank == 0:
+        print("Interpolating Coarse NS Flow", flush=True)
+    w0 = interpolate_initial_guess(msh, w_coarse_host, msh_f)
+    w, u, p = solve_navier_stokes(Pf, torch.from_numpy(w0).to(Pf.device), rank)
+    out = dict(msh=msh_f, w=w.cpu().numpy(), u=u.cpu().numpy(), p=p.cpu().numpy(), Re=Re, img_fname=img_fname,
+               channel_mesh_size=channel_mesh_size, flowrate_ratio=flowrate_ratio, newton=Pf.last_newton)
+    Pf.close()
+    return out
+
+
+def navier_stokes_channel_main(argv=None):
+    t0 = time.time()
+    r = solve_NS_flow(argv)
+    folder, _ = make_output_folder(r["Re"], r["img_fname"], r["channel_mesh_size"])
+    save_navier_stokes_solution(r["u"], r["p"], r["msh"], folder, r["Re"])
+    write_run_metadata(folder, r["Re"], r["img_fname"], r["flowrate_ratio"], r["channel_mesh_size"], r["msh"])
+    if _rank() == 0:
+        print(f"Run Time = {time.time() - t0:.2f} sec; output in {folder}", flush=True)
+    return r
+
+
+def stokes_channel_main(argv=None):
+    """StokesChannelFlow.py: linear P1-P1 pressure-stabilised Stokes, bcgs rtol=atol=1e-10 (:166)."""
+    argv = sys.argv if argv is None else argv
+    if len(argv) not in [3, 4]:
+        raise ValueError("Usage: script.py <img_fname> <flowrate_ratio> [<mesh_size>]")
+    img_fname, ratio = argv[1], float(argv[2])
+    mesh_size = float(argv[3]) if len(argv) == 4 else 0.25
+    t0 = time.perf_counter()
+    msh = generate_mesh(os.path.abspath(img_fname), mesh_size)
+    bcs = create_boundary_conditions(msh, ratio)
+    P = _problem(msh, bcs, ksp_type="bicgstab", ksp_rtol=1e-10, ksp_atol=1e-10)
+    print("\nStart Assembling Stiffness Matrix and Forcing Vector", flush=True)
+    U, res = P.stokes_solve()
+    print(f"Solve finished: {res.its} iterations, reason {res.reason}, {time.perf_counter() - t0:.2f} s", flush=True)
+    W = U.cpu().numpy().reshape(-1, 4)
+    write_xdmf("StokesChannelPressure", msh, "Pressure", W[:, 3])
+    write_xdmf("StokesChannelVelocity", msh, "Velocity", W[:, :3])
+    P.close()
+    return msh, W
+
+
+def duct_stokes_main(argv=None):
+    """DuctStokesFlow.py <gmsh_fname> <mesh_lc> <x_outlet> (:18-20): geometry :36-124, BCs :156-183,
+    printed norms :234-241 (labels as in the reference: 'L1' is the l2 norm of the coefficient vector)."""
+    argv = sys.argv if argv is None else argv
+    if len(argv) != 4:
+        raise ValueError("Usage: DuctStokesFlow.py <gmsh_fname> <mesh_lc> <x_outlet>")
+    gmsh_fname, mesh_lc, x_outlet = argv[1], float(argv[2]), float(argv[3])
+    msh = M.duct_mesh(lc_to_cells(mesh_lc, x_outlet), x_outlet)
+    M.write_msh2(msh, f"{gmsh_fname}.msh")                        # gmsh.write(f'{gmsh_fname}.msh') :141
+    P = _problem(msh, B.duct_bcs(msh))
+    U, res = P.stokes_solve()
+    W = U.cpu().numpy().reshape(-1, 4)
+    u, p = W[:, :3], W[:, 3]
+    print(f"L1 norm of velocity coefficient vector: {np.linalg.norm(u.ravel())}")
+    print(f"L1 norm of pressure coefficient vector: {np.linalg.norm(p)}")
+    print(f"Linf norm of pressure coefficient vector: {np.abs(u).max()}")
+    print(f"Linf norm of pressure coefficient vector: {np.abs(p).max()}")
+    write_xdmf("StokesDuctPressure", msh, "f", p)
+    write_xdmf("StokesDuctVelcoity", msh, "f", u)                 # (sic) file name of the reference :255
+    P.close()
+    return msh, W, res
+
+
+def lid_driven_main(argv=None):
+    """LidDrivenNavierStokesFlow.py <Re> [<NumCells>=64] (:17-23) on the 3-D unit cube:
+    lid y=1 moving with (1,0,0), no-slip elsewhere, p=0 at the origin (:57-77); Stokes then Newton."""
+    import torch
+    from .solver import solve_navier_stokes
+    argv = sys.argv if argv is None else argv
+    if len(argv) not in [2, 3]:
+        raise ValueError("Usage: LidDrivenNavierStokesFlow.py <Re> [<NumCells>]")
+    Re = int(argv[1])
+    n = int(argv[2]) if len(argv) == 3 else 64
+    t0 = time.time()
+    msh = M.cavity_mesh(n)
+    print(f"Pressure Degress of Freedom: {msh.num_nodes}")
+    print(f"Velocity Degress of Freedom: {msh.num_nodes}")
+    P = _problem(msh, B.cavity_bcs(msh), reynolds=float(Re))
+    U, res = P.stokes_solve()
+    print("Solved Stokes Flow")
+    w, u, p = solve_navier_stokes(P, U.clone())
+    print(f"run time = {time.time() - t0: 0.2f} sec")
+    write_xdmf(f"NavierStokesLidDrivenPressureLinear{Re}", msh, "Pressure", p.cpu().numpy())
+    write_xdmf(f"NavierStokesLidDrivenPressureVelocity{Re}", msh, "Velocity", u.cpu().numpy())
+    r = P.last_newton
+    P.close()
+    return msh, w.cpu().numpy(), r

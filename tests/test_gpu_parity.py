@@ -331,3 +331,22 @@ def test_rccl_path_single_rank(gpu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
+    """The reference's command lines end to end (tiny meshes): continuation Stokes -> coarse NS -> fine NS,
+    output folder + XDMF + RunParameters.txt; duct Stokes norms; 3-D cavity."""
+    import os
+    from stabilized_navier_stokes_flow_fenicsx_amd import drivers as D
+    monkeypatch.chdir(tmp_path)
+    r = D.navier_stokes_channel_main(["NavierStokesChannelFlow.py", "5", "./InletImages/Synthetic.png", "0.5", "0.2"])
+    assert r["newton"].reason > 0
+    folder = tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC02_Synthetic"
+    assert (folder / "Re5ChannelVelocity.xdmf").exists() and (folder / "RunParameters.txt").exists()
+    u = np.fromfile(folder / "Re5ChannelVelocity_Velocity.bin").reshape(-1, 3)
+    assert u.shape[0] == r["msh"].num_nodes and abs(u[:, 0].max()) > 0.5
+    msh, W, res = D.duct_stokes_main(["DuctStokesFlow.py", "ductmesh", "0.25", "2.0"])
+    assert res.reason > 0 and os.path.exists("ductmesh.msh") and os.path.exists("StokesDuctVelcoity.xdmf")
+    assert "L1 norm of velocity coefficient vector" in capsys.readouterr().out
+    msh, w, nres = D.lid_driven_main(["LidDrivenNavierStokesFlow.py", "10", "6"])
+    assert nres.reason > 0 and msh.num_tets == 6 ** 4
