@@ -50,12 +50,11 @@ def parse_arguments(argv=None):
     if len(argv) not in [4, 5]:
         raise ValueError("Usage: script.py <Re> <img_fname> <flowrate_ratio> [<channel_mesh_size>]")
     Re = int(argv[1])
-    img_fname = argv[2]
-    if hasattr(img_fname, "removeprefix"):
-        img_fname = img_fname.removeprefix(".")
-    elif img_fname.startswith("."):
-        img_fname = img_fname[1:]
-    img_fname = os.getcwd() + img_fname if not os.path.isabs(img_fname) else img_fname
+    given = argv[2]
+    img_fname = given[1:] if given.startswith(".") else given         # str.removeprefix(".")  (:87)
+    img_fname = os.getcwd() + img_fname                                # (:88-89)
+    if os.path.isabs(given) and os.path.exists(given):                 # leniency: an existing absolute path is used as is
+        img_fname = given
     flowrate_ratio = float(argv[3])
     channel_mesh_size = float(argv[4]) if len(argv) == 5 else 0.1
     return Re, img_fname, flowrate_ratio, channel_mesh_size
