@@ -131,6 +131,18 @@ int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_i
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
 
+/* In-process "team" communicator (TEST TRANSPORT): N ranks = N host threads of one
+ * process sharing one GPU; halo exchange / all-reduce / all-gather are emulated with
+ * barriers and device copies so the N-rank algorithm can be verified on a 1-GPU box.
+ * Every rank (thread) attaches its own handle; all collective calls must then be made
+ * concurrently from the N threads.  Never used by bench.py or the drivers.          */
+int sns_team_create(int nranks, void** team_out);
+int sns_team_destroy(void* team);
+int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
+                    int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
+                    const int32_t* send_ptr, const int32_t* send_idx,
+                    const int32_t* recv_ptr, const int32_t* recv_idx);
+
 /* ---- hot path --------------------------------------------------------------*/
 /* NonlinearPDE_SNESProblem.F (:51-67): F(w) incl. lifting and F_B = w_B - g.
  * form = SNS_FORM_NS, or SNS_FORM_STOKES for the linear residual A w - b.     */

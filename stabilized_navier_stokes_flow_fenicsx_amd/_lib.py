@@ -64,6 +64,9 @@ _SIGNATURES = [
                                 C.POINTER(C.c_int64)]),
     ("sns_comm_unique_id", C.c_int, [C.c_char_p]),
     ("sns_attach_comm", C.c_int, [_H, C.c_int, C.c_int, C.c_char_p, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
+    ("sns_team_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("sns_team_destroy", C.c_int, [_P]),
+    ("sns_attach_team", C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
     ("sns_residual", C.c_int, [_H, C.c_int, _P, _P]),
     ("sns_jacobian", C.c_int, [_H, C.c_int, _P, _P]),
     ("sns_spmv", C.c_int, [_H, _P, _P]),

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "sns_comm.h"
 #include "sns_internal.h"
 #include "sns_kernels.h"
 
@@ -58,15 +59,6 @@ static int dev_upload(T** p, const std::vector<T>& v, hipStream_t) {
     return SNS_OK;
 }
 
-struct Comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1;
-    std::vector<int> nbr;
-    std::vector<int32_t> send_ptr, recv_ptr;     // host copies (counts in nodes)
-    int32_t *send_idx = nullptr, *recv_idx = nullptr;
-    double *send_buf = nullptr, *recv_buf = nullptr;
-};
-
 }  // namespace sns
 
 using namespace sns;
@@ -110,6 +102,14 @@ struct sns_ctx {
     sns_timings tm{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<Comm> comm;
+    // distributed coarsest level: global dense inverse, replicated on every rank
+    int cg_maxn = 0;                              // padded owned coarsest nodes per rank
+    int cg_N = 0;                                 // 4 * nranks * cg_maxn (0 = not used)
+    std::vector<int> cg_counts;                   // owned coarsest nodes of every rank
+    int32_t* cg_colmap = nullptr;                 // local coarsest node -> global (padded) node id
+    double *cg_rows = nullptr, *cg_full = nullptr, *cg_send = nullptr, *cg_recv = nullptr;
+    std::vector<std::vector<int32_t>> ghost_gid;  // per level: (owner rank, owner-local id) of each ghost node
+    std::vector<std::vector<int32_t>> ghost_own;
     std::unique_ptr<HostPattern> pattern;      // kept until the (lazy) hierarchy build
     // optional per-launch timing of the fine-level SpMV family
     bool time_kernels = false;
@@ -166,9 +166,7 @@ void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
 }
 // sum `count` device doubles over the ranks (no-op without a communicator)
 int allreduce(sns_ctx* h, double* buf_dev, int count) {
-    if (h->comm && h->comm->comm)      // also with one rank: keeps the RCCL path exercised by 1-GPU tests
-        NCCL_TRY(ncclAllReduce(buf_dev, buf_dev, count, ncclDouble, ncclSum, h->comm->comm, h->stream));
-    return SNS_OK;
+    return comm_allreduce_sum(h->comm.get(), buf_dev, count, h->stream);
 }
 int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
     reduce_local(h, nblocks, nred, dst_dev);
@@ -182,31 +180,13 @@ int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
     return SNS_OK;
 }
 
-int halo_exchange(sns_ctx* h, double* x) {
+// fill the ghost tail of a level-l vector from the owning ranks
+int exchange_level(sns_ctx* h, int l, double* x) {
     Comm* c = h->comm.get();
-    if (!c || !c->comm || c->nranks <= 1 || c->nbr.empty()) return SNS_OK;
-    const int nn = (int)c->nbr.size();
-    const int32_t ns = c->send_ptr[nn], nr = c->recv_ptr[nn];
-    if (ns > 0)
-        hipLaunchKernelGGL(k_pack, dim3((4 * (int64_t)ns + 255) / 256), dim3(256), 0, h->stream, ns, c->send_idx, x,
-                           c->send_buf);
-    NCCL_TRY(ncclGroupStart());
-    for (int k = 0; k < nn; ++k) {
-        const int32_t s0 = c->send_ptr[k], s1 = c->send_ptr[k + 1];
-        const int32_t r0 = c->recv_ptr[k], r1 = c->recv_ptr[k + 1];
-        if (s1 > s0)
-            NCCL_TRY(ncclSend(c->send_buf + 4 * (int64_t)s0, 4 * (size_t)(s1 - s0), ncclDouble, c->nbr[k], c->comm,
-                              h->stream));
-        if (r1 > r0)
-            NCCL_TRY(ncclRecv(c->recv_buf + 4 * (int64_t)r0, 4 * (size_t)(r1 - r0), ncclDouble, c->nbr[k], c->comm,
-                              h->stream));
-    }
-    NCCL_TRY(ncclGroupEnd());
-    if (nr > 0)
-        hipLaunchKernelGGL(k_unpack, dim3((4 * (int64_t)nr + 255) / 256), dim3(256), 0, h->stream, nr, c->recv_idx,
-                           c->recv_buf, x);
-    return SNS_OK;
+    if (!c || !c->active() || c->nranks <= 1 || (size_t)l >= c->plans.size()) return SNS_OK;
+    return comm_exchange(c, c->plans[l], x, h->stream);
 }
+int halo_exchange(sns_ctx* h, double* x) { return exchange_level(h, 0, x); }
 
 // Per-launch timing of the level-0 SpMV family (bench.py roofline leg): event pairs are
 // recorded around every fine-level launch while h->time_kernels is set and resolved after
@@ -257,24 +237,99 @@ int upload_pattern(Level& L, const HostPattern& P, int32_t** slot_row, hipStream
     return SNS_OK;
 }
 
-// Build the aggregation hierarchy (symbolic, once per mesh).
+// global sums of a few host doubles (collective; identity without a communicator)
+int global_sum(sns_ctx* h, double* v, int count) {
+    Comm* c = h->comm.get();
+    if (!c || !c->active() || c->nranks <= 1) return SNS_OK;
+    HIP_TRY(hipMemcpy(h->d_scal + 64, v, count * sizeof(double), hipMemcpyHostToDevice));
+    SNS_TRY(comm_allreduce_sum(c, h->d_scal + 64, count, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(v, h->d_scal + 64, count * sizeof(double), hipMemcpyDeviceToHost));
+    return SNS_OK;
+}
+
+// Build the aggregation hierarchy (symbolic, once per mesh; collective over the ranks).
+// Aggregates never cross ranks, but the Galerkin operators keep every cross-rank coupling:
+// a ghost fine node's aggregate becomes a ghost coarse node, and each level gets its own
+// halo plan derived from the finer one.  With one rank this is plain serial aggregation.
 int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     const sns_options& o = h->opt;
+    Comm* c = h->comm.get();
+    const bool dist = c && c->active() && c->nranks > 1;
     HostPattern cur = fine;
-    int32_t n_active = h->n_owned;
+    int32_t n_owned = h->n_owned;
     // levels/side arrays must not reallocate while references into them are alive
     const size_t cap = (size_t)std::max(2, o.amg_max_levels) + 2;
     h->levels.reserve(cap);
     h->slot_row.reserve(cap);
     h->empty_c.reserve(cap);
     h->pong.reserve(cap);
+    if (dist) c->plans.reserve(cap);
+    h->ghost_gid.assign(1, {});
+    h->ghost_own.assign(1, {});
+    const int per_rank_coarse = dist ? std::max(1, o.amg_coarse_size / c->nranks) : o.amg_coarse_size;
+    if (dist && !h->levels[0].xg) {
+        SNS_TRY(dev_alloc(&h->levels[0].xg, 4 * (size_t)h->levels[0].n));
+        HIP_TRY(hipMemset(h->levels[0].xg, 0, 4 * (size_t)h->levels[0].n * sizeof(double)));
+    }
     for (int l = 0; l + 1 < o.amg_max_levels; ++l) {
-        if (n_active <= o.amg_coarse_size) break;
-        HostAggregation A;
-        build_aggregation_active(cur, n_active, std::max(2, o.amg_agg_size), A);
-        if (A.nc >= n_active || A.nc == 0) break;              // no progress
+        double flag[1] = {n_owned > per_rank_coarse ? 1.0 : 0.0};
+        SNS_TRY(global_sum(h, flag, 1));
+        if (flag[0] == 0.0) break;
+        std::vector<int32_t> agg;
+        int32_t nc_owned = 0;
+        aggregate_nodes(cur, n_owned, std::max(2, o.amg_agg_size), agg, nc_owned);
+        double prog[2] = {(double)n_owned, (double)nc_owned};
+        SNS_TRY(global_sum(h, prog, 2));
+        if (prog[1] >= prog[0] || prog[1] == 0.0) break;      // no progress anywhere
+        int32_t nc_total = nc_owned;
+        Plan cplan;
+        std::vector<int32_t> g_own, g_gid;                     // ghost coarse nodes: owner rank, owner-local id
         Level& L = h->levels[l];
-        L.nc = A.nc;
+        if (dist) {
+            const Plan& p = c->plans[l];
+            std::vector<double> ids((size_t)4 * cur.n, -1.0);
+            for (int32_t i = 0; i < n_owned; ++i) ids[(size_t)4 * i] = (double)agg[i];
+            HIP_TRY(hipMemcpy(L.xg, ids.data(), ids.size() * sizeof(double), hipMemcpyHostToDevice));
+            SNS_TRY(comm_exchange(c, p, L.xg, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(ids.data(), L.xg, ids.size() * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemset(L.xg, 0, ids.size() * sizeof(double)));
+            cplan.nbr = p.nbr;
+            cplan.send_ptr.assign(1, 0);
+            cplan.recv_ptr.assign(1, 0);
+            for (size_t k = 0; k < p.nbr.size(); ++k) {
+                std::vector<int32_t> u;
+                for (int32_t q = p.recv_ptr[k]; q < p.recv_ptr[k + 1]; ++q) {
+                    const int32_t rid = (int32_t)ids[(size_t)4 * p.h_recv_idx[q]];
+                    if (rid < 0) { set_error("hierarchy: ghost node without an aggregate on its owner"); return SNS_E_COMM; }
+                    u.push_back(rid);
+                }
+                std::sort(u.begin(), u.end());
+                u.erase(std::unique(u.begin(), u.end()), u.end());
+                for (int32_t q = p.recv_ptr[k]; q < p.recv_ptr[k + 1]; ++q) {
+                    const int32_t gnode = p.h_recv_idx[q];
+                    const int32_t rid = (int32_t)ids[(size_t)4 * gnode];
+                    agg[gnode] = nc_total + (int32_t)(std::lower_bound(u.begin(), u.end(), rid) - u.begin());
+                }
+                for (size_t q = 0; q < u.size(); ++q) {
+                    cplan.h_recv_idx.push_back(nc_total + (int32_t)q);
+                    g_own.push_back(p.nbr[k]);
+                    g_gid.push_back(u[q]);
+                }
+                nc_total += (int32_t)u.size();
+                cplan.recv_ptr.push_back((int32_t)cplan.h_recv_idx.size());
+                std::vector<int32_t> sset;
+                for (int32_t q = p.send_ptr[k]; q < p.send_ptr[k + 1]; ++q) sset.push_back(agg[p.h_send_idx[q]]);
+                std::sort(sset.begin(), sset.end());
+                sset.erase(std::unique(sset.begin(), sset.end()), sset.end());
+                cplan.h_send_idx.insert(cplan.h_send_idx.end(), sset.begin(), sset.end());
+                cplan.send_ptr.push_back((int32_t)cplan.h_send_idx.size());
+            }
+        }
+        HostAggregation A;
+        build_coarse_from_agg(cur, n_owned, agg, nc_owned, nc_total, A);
+        L.nc = nc_owned;
         SNS_TRY(dev_upload(&L.agg, A.agg, h->stream));
         SNS_TRY(dev_upload(&L.m_ptr, A.m_ptr, h->stream));
         SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
@@ -285,26 +340,62 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         h->empty_c.push_back(nullptr);
         h->pong.push_back(nullptr);
         Level& C = h->levels.back();
-        Level& L0 = h->levels[l];                              // re-fetch (emplace_back may have moved storage)
-        if (&L0 != &L) { set_error("internal: level storage moved"); return SNS_E_STATE; }
+        if (&h->levels[l] != &L) { set_error("internal: level storage moved"); return SNS_E_STATE; }
         SNS_TRY(upload_pattern(C, A.coarse, &h->slot_row.back(), h->stream));
-        C.n_owned = C.n;
+        C.n_owned = nc_owned;
         SNS_TRY(alloc_level_vectors(C));
         SNS_TRY(dev_alloc(&h->pong.back(), 4 * (size_t)C.n));
         HIP_TRY(hipMemset(h->pong.back(), 0, 4 * (size_t)C.n * sizeof(double)));
+        if (dist) {
+            SNS_TRY(dev_alloc(&C.xg, 4 * (size_t)C.n));
+            HIP_TRY(hipMemset(C.xg, 0, 4 * (size_t)C.n * sizeof(double)));
+            SNS_TRY(plan_upload(cplan));
+            c->plans.push_back(std::move(cplan));
+        }
+        h->ghost_own.push_back(std::move(g_own));
+        h->ghost_gid.push_back(std::move(g_gid));
         if (l == 0) {
-            SNS_TRY(dev_alloc(&h->empty_c[0], 4 * (size_t)A.nc));
-            hipLaunchKernelGGL(k_empty_coarse, dim3((4 * (int64_t)A.nc + 255) / 256), dim3(256), 0, h->stream,
-                               A.nc, L.m_ptr, L.m_idx, L.free_mask, h->empty_c[0]);
+            SNS_TRY(dev_alloc(&h->empty_c[0], 4 * (size_t)std::max(1, nc_owned)));
+            if (nc_owned > 0)
+                hipLaunchKernelGGL(k_empty_coarse, dim3((unsigned)((4 * (int64_t)nc_owned + 255) / 256)), dim3(256), 0,
+                                   h->stream, nc_owned, L.m_ptr, L.m_idx, L.free_mask, h->empty_c[0]);
         }
         cur = std::move(A.coarse);
-        n_active = cur.n;
+        n_owned = nc_owned;
     }
     Level& last = h->levels.back();
-    if (h->levels.size() > 1 && last.n <= std::max(o.amg_coarse_size, 40)) {
-        const size_t N = 4 * (size_t)last.n;
-        SNS_TRY(dev_alloc(&last.dense_inv, N * N));
-        SNS_TRY(dev_alloc(&h->d_piv, N));
+    if (h->levels.size() > 1) {
+        if (!dist) {
+            if (last.n <= std::max(o.amg_coarse_size, 40)) {
+                const size_t N = 4 * (size_t)last.n;
+                SNS_TRY(dev_alloc(&last.dense_inv, N * N));
+                SNS_TRY(dev_alloc(&h->d_piv, N));
+            }
+        } else {
+            // global dense coarsest solve, replicated on every rank: rank r's node i -> padded id r*maxn + i
+            std::vector<double> cnt(c->nranks, 0.0);
+            cnt[c->rank] = (double)last.n_owned;
+            SNS_TRY(global_sum(h, cnt.data(), c->nranks));
+            int maxn = 0;
+            h->cg_counts.resize(c->nranks);
+            for (int r = 0; r < c->nranks; ++r) { h->cg_counts[r] = (int)cnt[r]; maxn = std::max(maxn, (int)cnt[r]); }
+            const int N = 4 * c->nranks * std::max(1, maxn);
+            if (N <= 640) {
+                h->cg_maxn = std::max(1, maxn);
+                h->cg_N = N;
+                std::vector<int32_t> cmap((size_t)last.n, 0);
+                for (int32_t i = 0; i < last.n_owned; ++i) cmap[i] = c->rank * h->cg_maxn + i;
+                const auto& go = h->ghost_own.back();
+                const auto& gg = h->ghost_gid.back();
+                for (size_t q = 0; q < go.size(); ++q) cmap[(size_t)last.n_owned + q] = go[q] * h->cg_maxn + gg[q];
+                SNS_TRY(dev_upload(&h->cg_colmap, cmap, h->stream));
+                SNS_TRY(dev_alloc(&h->cg_rows, (size_t)4 * h->cg_maxn * N));
+                SNS_TRY(dev_alloc(&h->cg_full, (size_t)N * N));
+                SNS_TRY(dev_alloc(&h->cg_send, (size_t)4 * h->cg_maxn));
+                SNS_TRY(dev_alloc(&h->cg_recv, (size_t)N));
+                SNS_TRY(dev_alloc(&h->d_piv, (size_t)N));
+            }
+        }
     }
     h->tm.amg_levels = (int)h->levels.size();
     return SNS_OK;
@@ -353,7 +444,7 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
 // operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at 1.5/|lambda|max (smoothing-optimal damping is ~4/(3 lambda_max)).
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     Level& L = h->levels[l];
-    const int32_t rows = (l == 0) ? h->n_owned : L.n;
+    const int32_t rows = L.n_owned;
     const int64_t nd = 4 * (int64_t)rows;
     const int g = vec_grid(nd), g4 = (int)((nd + 255) / 256);
     double* x = h->pong[l];
@@ -387,10 +478,10 @@ int pc_setup(sns_ctx* h) {
     const int nl = (h->opt.pc_type == SNS_PC_AMG) ? (int)h->levels.size() : 1;
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
-        const int32_t rows = (l == 0) ? h->n_owned : L.n;
+        const int32_t rows = L.n_owned;
         hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
-        if (h->opt.pc_type == SNS_PC_AMG && !(L.dense_inv && l + 1 == nl)) {
+        if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             double lam = 0.0;
             SNS_TRY(estimate_lambda_max(h, l, &lam));
             L.lambda_max = lam;
@@ -403,6 +494,19 @@ int pc_setup(sns_ctx* h) {
             hipLaunchKernelGGL(k_galerkin, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, C.nnzb,
                                L.r_ptr, L.r_idx, h->slot_row[l], L.colind, L.free_mask, L.vals, h->slot_row[l + 1],
                                C.colind, (l == 0) ? h->empty_c[0] : (const uint8_t*)nullptr, C.vals);
+        } else if (h->cg_N > 0 && nl > 1) {
+            // distributed coarsest level: my rows of the GLOBAL dense matrix -> all-gather -> replicated inverse
+            const int N = h->cg_N, mr = 4 * h->cg_maxn;
+            HIP_TRY(hipMemsetAsync(h->cg_rows, 0, (size_t)mr * N * sizeof(double), h->stream));
+            const int64_t nth = L.nnzb * 16;
+            if (nth > 0)
+                hipLaunchKernelGGL(k_bsr_to_dense_map, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream,
+                                   L.n_owned, L.rowptr, L.colind, L.vals, h->cg_colmap, N, h->cg_rows);
+            // padding rows (ranks with fewer nodes than maxn) get a unit diagonal
+            hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(256), 0, h->stream, 4 * L.n_owned, mr,
+                               h->comm->rank * mr, N, h->cg_rows);
+            SNS_TRY(comm_allgather(h->comm.get(), h->cg_rows, h->cg_full, mr * N, h->stream));
+            hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(1024), 0, h->stream, N, h->cg_full, h->d_piv, h->d_sing);
         } else if (L.dense_inv && nl > 1) {
             const int N = 4 * L.n;
             HIP_TRY(hipMemsetAsync(L.dense_inv, 0, (size_t)N * N * sizeof(double), h->stream));
@@ -426,14 +530,26 @@ int pc_setup(sns_ctx* h) {
 // V-cycle on level l: x <- approx A_l^-1 b  (x overwritten; zero initial guess)
 int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     Level& L = h->levels[l];
-    const int32_t rows = (l == 0) ? h->n_owned : L.n;
+    const int32_t rows = L.n_owned;
     const bool last = (l + 1 == (int)h->levels.size());
     const double om = L.omega;
     const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
     if (last) {
+        if (h->cg_N > 0) {
+            const int N = h->cg_N, mr = 4 * h->cg_maxn;
+            HIP_TRY(hipMemsetAsync(h->cg_send, 0, mr * sizeof(double), h->stream));
+            if (rows > 0)
+                HIP_TRY(hipMemcpyAsync(h->cg_send, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice,
+                                       h->stream));
+            SNS_TRY(comm_allgather(h->comm.get(), h->cg_send, h->cg_recv, mr, h->stream));
+            if (rows > 0)
+                hipLaunchKernelGGL(k_dense_matvec, dim3((4 * rows + 3) / 4), dim3(256), 0, h->stream, N,
+                                   h->cg_full + (size_t)h->comm->rank * mr * N, h->cg_recv, x, 4 * rows);
+            return SNS_OK;
+        }
         if (L.dense_inv) {
             const int N = 4 * L.n;
-            hipLaunchKernelGGL(k_dense_matvec, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_inv, b, x);
+            hipLaunchKernelGGL(k_dense_matvec, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_inv, b, x, N);
             return SNS_OK;
         }
         // coarsest level too large for the dense solve: a fixed number of Jacobi sweeps (still a linear operator)
@@ -450,17 +566,24 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
-    hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+    if (rows > 0) hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
     for (int s = 1; s < nu; ++s) {
         launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
         std::swap(cur, oth);
     }
-    launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, nullptr);
+    if (L.xg) {      // distributed: true residual needs the neighbours' iterate; smoothing itself stays rank-local
+        HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        SNS_TRY(exchange_level(h, l, L.xg));
+        launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0, nullptr);
+    } else {
+        launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, nullptr);
+    }
     Level& C = h->levels[l + 1];
-    hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n + 255) / 256)), dim3(256), 0, h->stream, C.n,
-                       L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
+    if (C.n_owned > 0)
+        hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                           C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
     SNS_TRY(vcycle(h, l + 1, C.b, C.x));
-    hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
+    if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     for (int s = 0; s < nu; ++s) {
         launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
         std::swap(cur, oth);
@@ -909,9 +1032,11 @@ int sns_destroy(sns_handle h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    fr(h->cg_colmap); fr(h->cg_rows); fr(h->cg_full); fr(h->cg_send); fr(h->cg_recv);
+    for (auto& L : h->levels) fr(L.xg);
     if (h->comm) {
-        fr(h->comm->send_idx); fr(h->comm->recv_idx); fr(h->comm->send_buf); fr(h->comm->recv_buf);
-        if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
+        for (auto& p : h->comm->plans) plan_free(p);
+        if (h->comm->nccl) (void)ncclCommDestroy(h->comm->nccl);
     }
     delete h;
     return SNS_OK;
@@ -951,10 +1076,11 @@ int sns_comm_unique_id(char id_out[128]) {
     return SNS_OK;
 }
 
-int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int32_t n_owned, int n_nbr,
-                    const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
-                    const int32_t* recv_idx) {
-    if (!h || nranks < 1 || rank < 0 || rank >= nranks || n_owned < 0 || n_owned > h->n) {
+static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Team* team, int32_t n_owned, int n_nbr,
+                         const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx,
+                         const int32_t* recv_ptr, const int32_t* recv_idx) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks || n_owned < 0 || n_owned > h->n || n_nbr < 0 ||
+        (n_nbr > 0 && (!nbr || !send_ptr || !recv_ptr))) {
         set_error("sns_attach_comm: bad arguments");
         return SNS_E_ARG;
     }
@@ -967,34 +1093,64 @@ int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int
     Comm& c = *h->comm;
     c.rank = rank;
     c.nranks = nranks;
+    c.team = team;
     if (uid) {
         ncclUniqueId id;
         std::memcpy(&id, uid, 128);
-        NCCL_TRY(ncclCommInitRank(&c.comm, nranks, id, rank));
-    }   // uid == NULL: local part only, the caller moves ghost values and reduces (tests)
+        NCCL_TRY(ncclCommInitRank(&c.nccl, nranks, id, rank));
+    }   // uid == NULL and no team: local part only, the caller moves ghost values and reduces (tests)
     h->n_owned = n_owned;
     h->levels[0].n_owned = n_owned;
-    c.nbr.assign(nbr, nbr + n_nbr);
-    c.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
-    c.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
-    const int32_t ns = c.send_ptr[n_nbr], nr = c.recv_ptr[n_nbr];
+    c.plans.reserve(64);
+    c.plans.emplace_back();
+    Plan& p = c.plans[0];
+    p.nbr.assign(nbr, nbr + n_nbr);
+    if (n_nbr > 0) {
+        p.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+        p.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+    } else {
+        p.send_ptr.assign(1, 0);
+        p.recv_ptr.assign(1, 0);
+    }
+    const int32_t ns = p.n_send(), nr = p.n_recv();
     for (int32_t i = 0; i < ns; ++i)
         if (send_idx[i] < 0 || send_idx[i] >= n_owned) { set_error("send_idx outside owned range"); return SNS_E_ARG; }
     for (int32_t i = 0; i < nr; ++i)
         if (recv_idx[i] < n_owned || recv_idx[i] >= h->n) { set_error("recv_idx outside ghost range"); return SNS_E_ARG; }
-    std::vector<int32_t> si(send_idx, send_idx + ns), ri(recv_idx, recv_idx + nr);
-    SNS_TRY(dev_upload(&c.send_idx, si, nullptr));
-    SNS_TRY(dev_upload(&c.recv_idx, ri, nullptr));
-    SNS_TRY(dev_alloc(&c.send_buf, 4 * (size_t)ns));
-    SNS_TRY(dev_alloc(&c.recv_buf, 4 * (size_t)nr));
-    // ghost dofs never take part in the per-rank preconditioner's transfer operators
-    {
+    p.h_send_idx.assign(send_idx, send_idx + ns);
+    p.h_recv_idx.assign(recv_idx, recv_idx + nr);
+    SNS_TRY(plan_upload(p));
+    if (!c.active()) {
+        // no transport: the per-rank hierarchy must not reference ghost dofs at all
         std::vector<uint8_t> fm((size_t)4 * h->n);
         HIP_TRY(hipMemcpy(fm.data(), h->levels[0].free_mask, fm.size(), hipMemcpyDeviceToHost));
         for (size_t i = (size_t)4 * n_owned; i < fm.size(); ++i) fm[i] = 0;
         HIP_TRY(hipMemcpy(h->levels[0].free_mask, fm.data(), fm.size(), hipMemcpyHostToDevice));
     }
     return SNS_OK;
+}
+
+int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int32_t n_owned, int n_nbr,
+                    const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
+                    const int32_t* recv_idx) {
+    return attach_common(h, rank, nranks, uid, nullptr, n_owned, n_nbr, nbr, send_ptr, send_idx, recv_ptr, recv_idx);
+}
+
+int sns_team_create(int nranks, void** team_out) {
+    if (nranks < 1 || !team_out) return SNS_E_ARG;
+    *team_out = new Team(nranks);
+    return SNS_OK;
+}
+int sns_team_destroy(void* team) {
+    delete static_cast<Team*>(team);
+    return SNS_OK;
+}
+int sns_attach_team(sns_handle h, void* team, int rank, int nranks, int32_t n_owned, int n_nbr, const int32_t* nbr,
+                    const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
+                    const int32_t* recv_idx) {
+    if (!team || static_cast<Team*>(team)->n != nranks) { set_error("sns_attach_team: bad team"); return SNS_E_ARG; }
+    return attach_common(h, rank, nranks, nullptr, static_cast<Team*>(team), n_owned, n_nbr, nbr, send_ptr, send_idx,
+                         recv_ptr, recv_idx);
 }
 
 int sns_residual(sns_handle h, int form, const double* w, double* F) {

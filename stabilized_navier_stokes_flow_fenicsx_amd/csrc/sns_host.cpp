@@ -139,22 +139,27 @@ void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::v
     }
 }
 
-void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_agg, HostAggregation& A) {
-    aggregate_nodes(F, n_active, max_agg, A.agg, A.nc);
-    const int32_t nc = A.nc;
-    // members
+// Coarse pattern, member lists and Galerkin gather lists from a complete aggregate map.
+//   agg_all[j] : aggregate (LOCAL coarse id) of every local fine node; owned fine nodes map to
+//                [0, nc_owned), ghost fine nodes to [nc_owned, nc_total) (aggregates never cross ranks;
+//                a ghost node's aggregate is a ghost coarse node); -1 = node takes no part.
+// Rows are built for owned aggregates only; ghost coarse rows stay empty.
+void build_coarse_from_agg(const HostPattern& F, int32_t n_owned_fine, const std::vector<int32_t>& agg_all,
+                           int32_t nc_owned, int32_t nc_total, HostAggregation& A) {
+    A.agg = agg_all;
+    A.nc = nc_owned;
+    const int32_t nc = nc_owned;
     A.m_ptr.assign((size_t)nc + 1, 0);
-    for (int32_t i = 0; i < n_active; ++i) A.m_ptr[A.agg[i] + 1]++;
+    for (int32_t i = 0; i < n_owned_fine; ++i) A.m_ptr[A.agg[i] + 1]++;
     for (int32_t I = 0; I < nc; ++I) A.m_ptr[I + 1] += A.m_ptr[I];
-    A.m_idx.resize((size_t)n_active);
+    A.m_idx.resize((size_t)n_owned_fine);
     {
         std::vector<int32_t> cur(A.m_ptr.begin(), A.m_ptr.end() - 1);
-        for (int32_t i = 0; i < n_active; ++i) A.m_idx[cur[A.agg[i]]++] = i;
+        for (int32_t i = 0; i < n_owned_fine; ++i) A.m_idx[cur[A.agg[i]]++] = i;
     }
-    // coarse pattern + RAP gather lists: coarse slot (I,J) <- fine slots (i,j), i in I, j in J
     HostPattern& C = A.coarse;
-    C.n = nc;
-    C.rowptr.assign((size_t)nc + 1, 0);
+    C.n = nc_total;
+    C.rowptr.assign((size_t)nc_total + 1, 0);
     std::vector<std::vector<int32_t>> rows((size_t)nc);
 #pragma omp parallel
     {
@@ -165,8 +170,8 @@ void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_ag
             for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
                 int32_t i = A.m_idx[m];
                 for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
-                    int32_t j = F.colind[k];
-                    if (j < n_active) tmp.push_back(A.agg[j]);
+                    int32_t J = A.agg[F.colind[k]];
+                    if (J >= 0) tmp.push_back(J);
                 }
             }
             std::sort(tmp.begin(), tmp.end());
@@ -175,9 +180,10 @@ void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_ag
         }
     }
     for (int32_t I = 0; I < nc; ++I) C.rowptr[I + 1] = C.rowptr[I] + (int32_t)rows[I].size();
-    C.nnzb = C.rowptr[nc];
+    for (int32_t I = nc; I < nc_total; ++I) C.rowptr[I + 1] = C.rowptr[I];
+    C.nnzb = C.rowptr[nc_total];
     C.colind.resize((size_t)C.nnzb);
-    C.diag.resize((size_t)nc);
+    C.diag.assign((size_t)nc_total, 0);
     A.r_ptr.assign((size_t)C.nnzb + 1, 0);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int32_t I = 0; I < nc; ++I) {
@@ -186,10 +192,9 @@ void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_ag
         for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
             int32_t i = A.m_idx[m];
             for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
-                int32_t j = F.colind[k];
-                if (j >= n_active) continue;
-                int32_t s = C.rowptr[I] +
-                            (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), A.agg[j]) - rows[I].begin());
+                int32_t J = A.agg[F.colind[k]];
+                if (J < 0) continue;
+                int32_t s = C.rowptr[I] + (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), J) - rows[I].begin());
                 A.r_ptr[(size_t)s + 1]++;
             }
         }
@@ -205,15 +210,22 @@ void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_ag
             for (int32_t m = A.m_ptr[I]; m < A.m_ptr[I + 1]; ++m) {
                 int32_t i = A.m_idx[m];
                 for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
-                    int32_t j = F.colind[k];
-                    if (j >= n_active) continue;
-                    int32_t jj = (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), A.agg[j]) - rows[I].begin());
+                    int32_t J = A.agg[F.colind[k]];
+                    if (J < 0) continue;
+                    int32_t jj = (int32_t)(std::lower_bound(rows[I].begin(), rows[I].end(), J) - rows[I].begin());
                     int64_t s = C.rowptr[I] + jj;
                     A.r_idx[(size_t)(A.r_ptr[s] + fill[jj]++)] = k;
                 }
             }
         }
     }
+}
+
+void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_agg, HostAggregation& A) {
+    std::vector<int32_t> agg;
+    int32_t nc = 0;
+    aggregate_nodes(F, n_active, max_agg, agg, nc);
+    build_coarse_from_agg(F, n_active, agg, nc, nc, A);
 }
 
 void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A) {

@@ -40,6 +40,8 @@ void build_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets, HostPat
 void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A);
 // same, but only nodes [0, n_active) take part (distributed level 0: owned nodes only)
 void build_aggregation_active(const HostPattern& fine, int32_t n_active, int max_agg, HostAggregation& A);
+void build_coarse_from_agg(const HostPattern& F, int32_t n_owned_fine, const std::vector<int32_t>& agg_all,
+                           int32_t nc_owned, int32_t nc_total, HostAggregation& A);
 
 // ---- device-side level of the operator hierarchy ----------------------------
 struct Level {
@@ -58,6 +60,7 @@ struct Level {
     uint8_t* free_mask = nullptr;        // 4*n: 1 where dof takes part in transfer (level 0: !bc), else all 1
     // work vectors (4*n doubles)
     double *x = nullptr, *b = nullptr, *r = nullptr;
+    double* xg = nullptr;                // distributed runs: copy of the iterate whose ghost tail is exchanged
     // coarsest level: dense inverse (4n x 4n), row-major
     double* dense_inv = nullptr;
     // block-Jacobi damping actually used on this level (<= amg_omega, limited by 1.5/|lambda|max(Dinv A))

@@ -52,7 +52,10 @@ __global__ void k_empty_coarse(int32_t nc, const int32_t* m_ptr, const int32_t* 
 __global__ void k_bsr_to_dense(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals,
                                double* D);
 __global__ void k_dense_inverse(int N, double* A, int* piv, int* singular);
-__global__ void k_dense_matvec(int N, const double* D, const double* x, double* y);
+__global__ void k_dense_matvec(int N, const double* D, const double* x, double* y, int nrows);
+__global__ void k_bsr_to_dense_map(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
+                                   const int32_t* colmap, int N, double* D);
+__global__ void k_pad_identity(int r0, int r1, int g0, int N, double* D);
 __global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
 __global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
 __global__ void k_fill_pattern(int64_t n, double* x);

@@ -903,17 +903,39 @@ __global__ __launch_bounds__(1024) void k_dense_inverse(int N, double* __restric
     }
 }
 
-// y = D x, dense N x N, one wave per row
+// y[0..nrows) = D[0..nrows, :] x, dense with N columns, one wave per row
 __global__ __launch_bounds__(256) void k_dense_matvec(int N, const double* __restrict__ D,
-                                                      const double* __restrict__ x, double* __restrict__ y) {
+                                                      const double* __restrict__ x, double* __restrict__ y,
+                                                      int nrows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= N) return;
+    if (row >= nrows) return;
     double s = 0.0;
     for (int c = lane; c < N; c += 64) s += D[(int64_t)row * N + c] * x[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) y[row] = s;
+}
+
+// owned rows of a small distributed BSR matrix -> rows of the global dense matrix (N columns),
+// column block of local node j = colmap[j]
+__global__ __launch_bounds__(256) void k_bsr_to_dense_map(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colind,
+                                                          const double* __restrict__ vals,
+                                                          const int32_t* __restrict__ colmap, int N,
+                                                          double* __restrict__ D) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 4;
+    const int e = (int)(gid & 15);
+    if (s >= rowptr[n_rows]) return;
+    int32_t row = 0;
+    while (rowptr[row + 1] <= s) ++row;
+    D[(int64_t)(4 * row + (e >> 2)) * N + 4 * colmap[colind[s]] + (e & 3)] = vals[s * 16 + e];
+}
+
+// rows [r0, r1) of a row block whose first row is global row g0: unit diagonal (padding dofs)
+__global__ __launch_bounds__(256) void k_pad_identity(int r0, int r1, int g0, int N, double* __restrict__ D) {
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) D[(int64_t)r * N + g0 + r] = 1.0;
 }
 
 // ============================================================================

@@ -109,6 +109,16 @@ class FlowProblem:
         return self
 
     def _attach_comm(self, part, group):
+        nb = np.ascontiguousarray(part.neighbors, dtype=np.int32)
+        sp_, si = np.ascontiguousarray(part.send_ptr, np.int32), np.ascontiguousarray(part.send_idx, np.int32)
+        rp, ri = np.ascontiguousarray(part.recv_ptr, np.int32), np.ascontiguousarray(part.recv_idx, np.int32)
+        if isinstance(group, Team):                    # tests: N ranks = N threads of this process
+            with torch.cuda.device(self.device):
+                check(self.lib.sns_attach_team(self.h, group.ptr, part.rank, part.nranks, part.n_owned, len(nb),
+                                               nb.ctypes.data, sp_.ctypes.data, si.ctypes.data, rp.ctypes.data,
+                                               ri.ctypes.data))
+            self.n_owned = part.n_owned
+            return
         if group == "local-only":                      # tests: owned/ghost split without a communicator
             box = [None]
         else:
@@ -120,9 +130,6 @@ class FlowProblem:
             if part.nranks > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                            group=group)
-        nb = np.ascontiguousarray(part.neighbors, dtype=np.int32)
-        sp_, si = np.ascontiguousarray(part.send_ptr, np.int32), np.ascontiguousarray(part.send_idx, np.int32)
-        rp, ri = np.ascontiguousarray(part.recv_ptr, np.int32), np.ascontiguousarray(part.recv_idx, np.int32)
         with torch.cuda.device(self.device):
             check(self.lib.sns_attach_comm(self.h, part.rank, part.nranks, box[0], part.n_owned, len(nb),
                                            nb.ctypes.data, sp_.ctypes.data, si.ctypes.data, rp.ctypes.data,
@@ -299,6 +306,43 @@ class FlowProblem:
         ms = C.c_double()
         check(self.lib.sns_bench_assemble(self.h, _FORMS[form], _ptr(w), _ptr(F), reps, C.byref(ms)))
         return ms.value
+
+
+class Team:
+    """In-process test transport (sns_team_*): N ranks = N threads sharing one GPU."""
+
+    def __init__(self, nranks: int):
+        self.lib = _lib.load()
+        self.n = nranks
+        p = C.c_void_p()
+        check(self.lib.sns_team_create(nranks, C.byref(p)))
+        self.ptr = p
+
+    def close(self):
+        if self.ptr:
+            self.lib.sns_team_destroy(self.ptr)
+            self.ptr = None
+
+    def run(self, fn):
+        """fn(rank, team) on N concurrent threads; returns the list of results, re-raises the first error."""
+        import threading
+        out, err = [None] * self.n, [None] * self.n
+
+        def work(r):
+            try:
+                out[r] = fn(r, self)
+            except BaseException as e:        # noqa: BLE001
+                err[r] = e
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(self.n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
 
 
 class NonlinearPDE_SNESProblem:

@@ -350,3 +350,42 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     assert "L1 norm of velocity coefficient vector" in capsys.readouterr().out
     msh, w, nres = D.lid_driven_main(["LidDrivenNavierStokesFlow.py", "10", "6"])
     assert nres.reason > 0 and msh.num_tets == 6 ** 4
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_n_rank_solver_through_team_transport(gpu, nranks):
+    """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
+    exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
+    GPU over the in-process team transport; RCCL only replaces the transport on a multi-GPU node."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
+    mask, g = B.duct_bcs(m).flatten()
+    Re = 12.0
+    Ps = gpu(m, (mask, g), reynolds=Re)
+    Us, rs = Ps.stokes_solve()
+    ws, ns = Ps.newton_solve(Us.clone())
+    Us, ws = Us.cpu().numpy(), ws.cpu().numpy()
+    Ps.close()
+    owner = PT.rcb_partition(m.points, nranks)
+    team = Team(nranks)
+
+    def work(rank, team):
+        part = PT.build_local_part(m, mask, g, owner, rank, nranks)
+        P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
+        U, r = P.stokes_solve()
+        w, n = P.newton_solve(U.clone())
+        out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n)
+        P.close()
+        return out
+
+    outs = team.run(work)
+    team.close()
+    Ug, wg = np.zeros(m.num_dofs), np.zeros(m.num_dofs)
+    for part, U, r, w, n in outs:
+        gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
+        Ug[gd], wg[gd] = U[:4 * part.n_owned], w[:4 * part.n_owned]
+        assert r.reason > 0 and n.reason == ns.reason and n.its == ns.its
+        assert (r.its, n.ksp_its) == (outs[0][2].its, outs[0][4].ksp_its)      # every rank took the same decisions
+    assert rel(Ug, Us) < 1e-6 and rel(wg, ws) < 1e-8
+    assert outs[0][2].its <= 2 * rs.its + 4                                   # coarse correction stays global
