@@ -1,0 +1,11 @@
+import sys, numpy as np, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
+from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+cells = eval(sys.argv[1]) if len(sys.argv) > 1 else (300, 75, 75)
+m = M.duct_mesh(cells, 4.0)
+P = FlowProblem(m, B.duct_bcs(m), reynolds=200.0)
+U, r = P.stokes_solve()
+for rep in range(2):
+    ms = P.bench_assemble(U, "ns", 5)
+    print(f"assemble J+F {ms:.3f} ms -> {2480.0*m.num_tets/ms/1e6:.1f} GB/s algorithmic", flush=True)

@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
 

@@ -1,7 +1,7 @@
 """N-rank solver logic on ONE GPU through the in-process team transport."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B, partition as PT
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem, Team
 

@@ -1,7 +1,7 @@
 """Parameter sweep of the Krylov/AMG knobs: time-to-solution of the first Newton linear solve."""
 import sys, time, itertools
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
 cells = eval(sys.argv[1]) if len(sys.argv) > 1 else (200, 50, 50)

@@ -1,6 +1,6 @@
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
 for cells, jit in [((300, 75, 75), 0.0), ((200, 50, 50), 0.2)]:

@@ -422,7 +422,7 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
     }
     Level& L = h->levels[0];
     if (want_matrix) {
-        const int64_t nth = L.nnzb * 16;
+        const int64_t nth = L.nnzb * 8;
         hipLaunchKernelGGL(k_gather_matrix, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.nnzb,
                            h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->bc_mask, h->Ke, L.vals);
         h->has_matrix = true;

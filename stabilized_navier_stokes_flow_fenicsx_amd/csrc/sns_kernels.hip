@@ -53,15 +53,19 @@ struct TetLds {
 __device__ __forceinline__ double phi_q(int q, int a) { return q == a ? QB : QA; }
 
 template <int FORM, bool corrected>
-__global__ __launch_bounds__(EL_TPB) void k_element(int64_t n_tets, const int32_t* __restrict__ tets,
+__global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int32_t* __restrict__ tets,
                                                     const double* __restrict__ pts,
                                                     const double* __restrict__ w,
                                                     const uint8_t* __restrict__ bc_mask,
                                                     const double* __restrict__ bc_val, double nu,
                                                     int store_K, double* __restrict__ Ke,
                                                     double* __restrict__ Fe) {
-    __shared__ TetLds sh[EL_TETS];
-    __shared__ double tile[EL_TPB * 17];
+    // staging data and the output transpose tile share LDS (the tile is written after a barrier
+    // that retires every read of the staging data): 34.8 KB per workgroup -> 4 workgroups per CU
+    constexpr size_t SH_BYTES = sizeof(TetLds) * EL_TETS, TILE_BYTES = sizeof(double) * EL_TPB * 17;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SH_BYTES > TILE_BYTES ? SH_BYTES : TILE_BYTES];
+    TetLds* sh = reinterpret_cast<TetLds*>(lds_raw);
+    double* tile = reinterpret_cast<double*>(lds_raw);
 
     const int tid = threadIdx.x;
     const int tl = tid >> 4;            // tet within workgroup
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(EL_TPB) void k_element(int64_t n_tets, const int32_
 
     // ---- transpose 256 blocks through LDS, store 1 KiB per wave instruction ----
     if (store_K) {
+        __syncthreads();                                    // all reads of the staging data are done
 #pragma unroll
         for (int e = 0; e < 16; ++e) tile[tid * 17 + e] = acc[e];
         __syncthreads();
@@ -377,7 +382,8 @@ SNS_INST_ELEMENT(SNS_FORM_NS, true)
 
 // BSR slot <- sum over its contributing element blocks (fixed order => bitwise
 // reproducible), Dirichlet rows AND columns zeroed, unit diagonal (:74).
-// 16 lanes per slot, lane = entry (c,d): each contribution is one 128-B line.
+// 8 lanes per slot, lane = two adjacent entries (16-B loads): each contribution is one
+// 128-B line; 4 independent accumulators keep 4 lines per group in flight.
 __global__ __launch_bounds__(256) void k_gather_matrix(int64_t nnzb, const int64_t* __restrict__ c_ptr,
                                                        const int32_t* __restrict__ c_idx,
                                                        const int32_t* __restrict__ slot_row,
@@ -385,22 +391,31 @@ __global__ __launch_bounds__(256) void k_gather_matrix(int64_t nnzb, const int64
                                                        const uint8_t* __restrict__ bc_mask,
                                                        const double* __restrict__ Ke, double* __restrict__ vals) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t s = gid >> 4;
-    const int e = (int)(gid & 15);
+    const int64_t s = gid >> 3;
+    const int e2 = (int)(gid & 7);                 // entries 2*e2, 2*e2+1 of the 4x4 block
     if (s >= nnzb) return;
     const int64_t k0 = c_ptr[s], k1 = c_ptr[s + 1];
-    double a0 = 0.0, a1 = 0.0;
+    const double2* __restrict__ K2 = reinterpret_cast<const double2*>(Ke);
+    double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, a2 = {0.0, 0.0}, a3 = {0.0, 0.0};
     int64_t k = k0;
-    for (; k + 1 < k1; k += 2) {
-        a0 += Ke[(int64_t)c_idx[k] * 16 + e];
-        a1 += Ke[(int64_t)c_idx[k + 1] * 16 + e];
+    for (; k + 3 < k1; k += 4) {
+        const int32_t i0 = c_idx[k], i1 = c_idx[k + 1], i2 = c_idx[k + 2], i3 = c_idx[k + 3];
+        const double2 v0 = K2[(int64_t)i0 * 8 + e2], v1 = K2[(int64_t)i1 * 8 + e2];
+        const double2 v2 = K2[(int64_t)i2 * 8 + e2], v3 = K2[(int64_t)i3 * 8 + e2];
+        a0.x += v0.x; a0.y += v0.y; a1.x += v1.x; a1.y += v1.y;
+        a2.x += v2.x; a2.y += v2.y; a3.x += v3.x; a3.y += v3.y;
     }
-    if (k < k1) a0 += Ke[(int64_t)c_idx[k] * 16 + e];
-    double v = a0 + a1;
+    for (; k < k1; ++k) {
+        const double2 v0 = K2[(int64_t)c_idx[k] * 8 + e2];
+        a0.x += v0.x; a0.y += v0.y;
+    }
+    double vx = (a0.x + a1.x) + (a2.x + a3.x), vy = (a0.y + a1.y) + (a2.y + a3.y);
     const int32_t row = slot_row[s], col = colind[s];
-    const int c = e >> 2, d = e & 3;
-    if (bc_mask[4 * (int64_t)row + c] | bc_mask[4 * (int64_t)col + d]) v = (row == col && c == d) ? 1.0 : 0.0;
-    vals[s * 16 + e] = v;
+    const int c = e2 >> 1, d0 = (e2 & 1) * 2;
+    const bool rb = bc_mask[4 * (int64_t)row + c];
+    if (rb | bc_mask[4 * (int64_t)col + d0]) vx = (row == col && c == d0) ? 1.0 : 0.0;
+    if (rb | bc_mask[4 * (int64_t)col + d0 + 1]) vy = (row == col && c == d0 + 1) ? 1.0 : 0.0;
+    reinterpret_cast<double2*>(vals)[s * 8 + e2] = make_double2(vx, vy);
 }
 
 // node residual <- sum of incident element residuals; F_B = w_B - g (:67)
