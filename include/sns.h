@@ -49,6 +49,7 @@ typedef struct sns_ctx* sns_handle;
 /* Krylov methods (snes_ksp_type :77, petsc_options :198-202) */
 #define SNS_KSP_BICGSTAB  0
 #define SNS_KSP_FGMRES    1
+#define SNS_KSP_TFQMR     2   /* the reference's snes_ksp_type (:77) */
 
 /* preconditioners */
 #define SNS_PC_NONE       0

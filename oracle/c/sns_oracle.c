@@ -1,0 +1,550 @@
+/*
+ * sns_oracle.c -- plain-C (OpenMP) CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE (see oracle/__init__.py): used only by tests/ and by
+ * bench.py's cpu_baseline leg ("port").  PARITY UNPINNED: the reference ships no
+ * fixtures for this path and cannot be executed here; this file restates
+ *   - the element forms  NavierStokes/NavierStokesChannelFlow.py:160-172 (Stokes),
+ *                        :220-251 (NS) and their exact derivative (:46)
+ *   - the assembly + Dirichlet semantics of the .F/.J callbacks (:51-75)
+ *   - the reference's linear algorithm: KSP tfqmr (:77,:199,:282) / bcgs
+ *     (StokesChannelFlow.py:166) with PETSc's default preconditioner, block-Jacobi
+ *     over the ranks with ILU(0) on each block -- here "rank" = OpenMP
+ *     thread block of contiguous node rows, ILU(0) on 4x4 nodal blocks.
+ * It is checked against oracle/element.py / assemble.py in tests/test_oracle_c.py.
+ *
+ * Build: make -C oracle/c   (gcc -O3 -march=x86-64-v3 -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QA 0.1381966011250105
+#define QB 0.5854101966249685
+
+static inline double phi_q(int q, int a) { return q == a ? QB : QA; }
+
+/* geometry of one tet: g[a][j] = d phi_a / d x_j, K = J^-1, returns |det J| */
+static double tet_geometry(const double X[4][3], double K[3][3], double g[4][3]) {
+    double J[3][3];
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = X[1][i] - X[0][i];
+        J[i][1] = X[2][i] - X[0][i];
+        J[i][2] = X[3][i] - X[0][i];
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double id = 1.0 / det;
+    K[0][0] = c00 * id; K[1][0] = c01 * id; K[2][0] = c02 * id;
+    K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+    K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+    K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+    K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    for (int j = 0; j < 3; ++j) {
+        g[1][j] = K[0][j]; g[2][j] = K[1][j]; g[3][j] = K[2][j];
+        g[0][j] = -(K[0][j] + K[1][j] + K[2][j]);
+    }
+    return fabs(det);
+}
+
+/* Stokes element matrix Ae[16][16] (row 4a+c, col 4b+d), :160-172 */
+static void stokes_element(const double X[4][3], double Ae[16][16]) {
+    double K[3][3], g[4][3];
+    const double det = tet_geometry(X, K, g);
+    const double vol = det / 6.0;
+    double h2 = 0.0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b) {
+            double d = 0.0;
+            for (int i = 0; i < 3; ++i) d += (X[a][i] - X[b][i]) * (X[a][i] - X[b][i]);
+            if (d > h2) h2 = d;
+        }
+    const double muT = 0.2 * h2;                       /* :169 */
+    memset(Ae, 0, sizeof(double) * 256);
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const double gab = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+            for (int i = 0; i < 3; ++i) {
+                Ae[4 * a + i][4 * b + i] = vol * gab;
+                Ae[4 * a + i][4 * b + 3] = -(vol / 4.0) * g[a][i];
+                Ae[4 * a + 3][4 * b + i] = (vol / 4.0) * g[b][i];
+            }
+            Ae[4 * a + 3][4 * b + 3] = muT * vol * gab;
+        }
+}
+
+/* NS element residual Re[16] and Jacobian Je[16][16], :220-251 + :46 */
+static void ns_element(const double X[4][3], const double W[16], double nu, double Re_[16], double Je[16][16]) {
+    double K[3][3], g[4][3];
+    const double det = tet_geometry(X, K, g);
+    const double wd = det / 24.0;
+    double G[3][3], trG = 0.0, GG = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            G[i][j] = K[0][i] * K[0][j] + K[1][i] * K[1][j] + K[2][i] * K[2][j];
+            GG += G[i][j] * G[i][j];
+            if (i == j) trG += G[i][j];
+        }
+    double gu[3][3], gp[3];
+    for (int j = 0; j < 3; ++j) {
+        gp[j] = 0.0;
+        for (int a = 0; a < 4; ++a) gp[j] += W[4 * a + 3] * g[a][j];
+        for (int i = 0; i < 3; ++i) {
+            gu[i][j] = 0.0;
+            for (int a = 0; a < 4; ++a) gu[i][j] += W[4 * a + i] * g[a][j];
+        }
+    }
+    const double divu = gu[0][0] + gu[1][1] + gu[2][2];
+    double gab[4][4], guga[4][3];
+    for (int a = 0; a < 4; ++a) {
+        for (int b = 0; b < 4; ++b) gab[a][b] = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+        for (int i = 0; i < 3; ++i) guga[a][i] = gu[i][0] * g[a][0] + gu[i][1] * g[a][1] + gu[i][2] * g[a][2];
+    }
+    memset(Re_, 0, sizeof(double) * 16);
+    memset(Je, 0, sizeof(double) * 256);
+    for (int q = 0; q < 4; ++q) {
+        double u[3] = {0, 0, 0}, p = 0.0;
+        for (int a = 0; a < 4; ++a) {
+            const double ph = phi_q(q, a);
+            for (int i = 0; i < 3; ++i) u[i] += ph * W[4 * a + i];
+            p += ph * W[4 * a + 3];
+        }
+        double Gu[3], conv[3], r[3], uGu = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            Gu[i] = G[i][0] * u[0] + G[i][1] * u[1] + G[i][2] * u[2];
+            uGu += u[i] * Gu[i];
+            conv[i] = gu[i][0] * u[0] + gu[i][1] * u[1] + gu[i][2] * u[2];           /* (u.grad)u :243 */
+        }
+        for (int j = 0; j < 3; ++j) r[j] = gu[0][j] * u[0] + gu[1][j] * u[1] + gu[2][j] * u[2] + gp[j];  /* :241 */
+        const double tau = 1.0 / sqrt(uGu + 36.0 * nu * nu * GG);                    /* :237-238 */
+        const double nuL = 1.0 / (trG * tau);                                        /* :249 */
+        const double t3 = tau * tau * tau;
+        double s[4];
+        for (int a = 0; a < 4; ++a) s[a] = r[0] * g[a][0] + r[1] * g[a][1] + r[2] * g[a][2];
+        for (int a = 0; a < 4; ++a) {
+            const double pa = phi_q(q, a);
+            for (int i = 0; i < 3; ++i)
+                Re_[4 * a + i] += wd * (conv[i] * pa + nu * guga[a][i] - p * g[a][i] + tau * u[i] * s[a] +
+                                        nuL * divu * g[a][i]);
+            Re_[4 * a + 3] += wd * (pa * divu + tau * s[a]);
+            for (int b = 0; b < 4; ++b) {
+                const double pb = phi_q(q, b);
+                const double ugb = u[0] * g[b][0] + u[1] * g[b][1] + u[2] * g[b][2];
+                double cu[3], cg[3];
+                for (int j = 0; j < 3; ++j) {
+                    const double dtau = -t3 * pb * Gu[j];
+                    const double dnuL = (tau / trG) * pb * Gu[j];
+                    cu[j] = dtau * s[a] + tau * (u[j] * gab[a][b] + pb * guga[a][j]);
+                    cg[j] = dnuL * divu + nuL * g[b][j];
+                }
+                const double A1 = pa * ugb + nu * gab[a][b] + tau * s[a] * pb;
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j)
+                        Je[4 * a + i][4 * b + j] += wd * (pa * pb * gu[i][j] + u[i] * cu[j] + g[a][i] * cg[j]);
+                    Je[4 * a + i][4 * b + i] += wd * A1;
+                    Je[4 * a + i][4 * b + 3] += wd * (-pb * g[a][i] + tau * u[i] * gab[a][b]);
+                    Je[4 * a + 3][4 * b + i] += wd * (pa * g[b][i] + cu[i]);
+                }
+                Je[4 * a + 3][4 * b + 3] += wd * tau * gab[a][b];
+            }
+        }
+    }
+}
+
+/* element-level entry points for tests: n tets, X [n][4][3], W [n][16] -> R [n][16], J [n][16][16] */
+void orc_ns_elements(int64_t n, const double* X, const double* W, double Re, double* R, double* J) {
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < n; ++t)
+        ns_element((const double(*)[3])(X + 12 * t), W + 16 * t, 1.0 / Re, R + 16 * t, (double(*)[16])(J + 256 * t));
+}
+void orc_stokes_elements(int64_t n, const double* X, double* A) {
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < n; ++t) stokes_element((const double(*)[3])(X + 12 * t), (double(*)[16])(A + 256 * t));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BSR pattern (rows sorted) from the connectivity.  Two calls: rowptr_out==NULL -> returns nnzb.
+ * ---------------------------------------------------------------------------------------------- */
+static int cmp_i32(const void* a, const void* b) { return (*(const int32_t*)a > *(const int32_t*)b) - (*(const int32_t*)a < *(const int32_t*)b); }
+
+int64_t orc_pattern(int32_t n, int64_t E, const int32_t* tets, int32_t* rowptr, int32_t* colind) {
+    int64_t* cnt = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+    for (int64_t t = 0; t < E; ++t)
+        for (int a = 0; a < 4; ++a) cnt[tets[4 * t + a] + 1] += 4;
+    for (int32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    int32_t* tmp = (int32_t*)malloc((size_t)cnt[n] * sizeof(int32_t));
+    int64_t* cur = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+    memcpy(cur, cnt, (size_t)n * sizeof(int64_t));
+    for (int64_t t = 0; t < E; ++t)
+        for (int a = 0; a < 4; ++a) {
+            const int32_t i = tets[4 * t + a];
+            for (int b = 0; b < 4; ++b) tmp[cur[i]++] = tets[4 * t + b];
+        }
+    int64_t nnzb = 0;
+    int32_t* len = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : nnzb)
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t* s = tmp + cnt[i];
+        const int64_t m = cnt[i + 1] - cnt[i];
+        qsort(s, (size_t)m, sizeof(int32_t), cmp_i32);
+        int32_t u = 0;
+        for (int64_t k = 0; k < m; ++k)
+            if (k == 0 || s[k] != s[k - 1]) s[u++] = s[k];
+        if (m == 0) { u = 0; }
+        len[i] = u;
+        nnzb += u;
+    }
+    if (rowptr) {
+        rowptr[0] = 0;
+        for (int32_t i = 0; i < n; ++i) rowptr[i + 1] = rowptr[i] + len[i];
+        for (int32_t i = 0; i < n; ++i) memcpy(colind + rowptr[i], tmp + cnt[i], (size_t)len[i] * sizeof(int32_t));
+    }
+    free(cnt); free(tmp); free(cur); free(len);
+    return nnzb;
+}
+
+static inline int32_t find_slot(const int32_t* rowptr, const int32_t* colind, int32_t i, int32_t j) {
+    int32_t lo = rowptr[i], hi = rowptr[i + 1] - 1;
+    while (lo <= hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (colind[mid] == j) return mid;
+        if (colind[mid] < j) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+/* Assemble (form 0 Stokes / 1 NS) into BSR vals [nnzb][16] and F [4n] with the reference's Dirichlet
+ * semantics (:65-67, :74).  Scatter with atomics-free colouring is overkill on the CPU: `omp atomic`. */
+int orc_assemble(int form, int32_t n, int64_t E, const double* pts, const int32_t* tets, const double* w, double Re,
+                 const uint8_t* mask, const double* g, const int32_t* rowptr, const int32_t* colind, double* vals,
+                 double* F) {
+    const int64_t nnzb = rowptr[n];
+    memset(vals, 0, (size_t)nnzb * 16 * sizeof(double));
+    memset(F, 0, (size_t)n * 4 * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < E; ++t) {
+        const int32_t* tv = tets + 4 * t;
+        double X[4][3], W[16], GW[16], Re_[16], Je[16][16];
+        for (int a = 0; a < 4; ++a) {
+            for (int i = 0; i < 3; ++i) X[a][i] = pts[3 * (int64_t)tv[a] + i];
+            for (int c = 0; c < 4; ++c) {
+                const int64_t d = 4 * (int64_t)tv[a] + c;
+                W[4 * a + c] = w ? w[d] : 0.0;
+                GW[4 * a + c] = mask[d] ? (g[d] - W[4 * a + c]) : 0.0;
+            }
+        }
+        if (form == 1) ns_element(X, W, 1.0 / Re, Re_, Je);
+        else {
+            stokes_element(X, Je);
+            for (int r = 0; r < 16; ++r) {
+                double s = 0.0;
+                for (int c = 0; c < 16; ++c) s += Je[r][c] * W[c];
+                Re_[r] = s;
+            }
+        }
+        for (int r = 0; r < 16; ++r) {                       /* lifting A0[:,B](g - x_B)  :65 */
+            double s = 0.0;
+            for (int c = 0; c < 16; ++c) s += Je[r][c] * GW[c];
+            Re_[r] += s;
+        }
+        for (int a = 0; a < 4; ++a) {
+            for (int c = 0; c < 4; ++c) {
+#pragma omp atomic
+                F[4 * (int64_t)tv[a] + c] += Re_[4 * a + c];
+            }
+            for (int b = 0; b < 4; ++b) {
+                const int32_t s = find_slot(rowptr, colind, tv[a], tv[b]);
+                double* dst = vals + 16 * (int64_t)s;
+                for (int c = 0; c < 4; ++c)
+                    for (int d = 0; d < 4; ++d) {
+#pragma omp atomic
+                        dst[4 * c + d] += Je[4 * a + c][4 * b + d];
+                    }
+            }
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < n; ++i) {
+        for (int32_t s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+            const int32_t j = colind[s];
+            for (int c = 0; c < 4; ++c)
+                for (int d = 0; d < 4; ++d)
+                    if (mask[4 * (int64_t)i + c] || mask[4 * (int64_t)j + d])
+                        vals[16 * (int64_t)s + 4 * c + d] = (i == j && c == d) ? 1.0 : 0.0;
+        }
+        for (int c = 0; c < 4; ++c) {
+            const int64_t d = 4 * (int64_t)i + c;
+            if (mask[d]) F[d] = (w ? w[d] : 0.0) - g[d];      /* set_bc(F, bc, x, -1)  :67 */
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * y = A x  (BSR4)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_spmv(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < n; ++i) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int32_t s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+            const double* v = vals + 16 * (int64_t)s;
+            const double* xx = x + 4 * (int64_t)colind[s];
+            a0 += v[0] * xx[0] + v[1] * xx[1] + v[2] * xx[2] + v[3] * xx[3];
+            a1 += v[4] * xx[0] + v[5] * xx[1] + v[6] * xx[2] + v[7] * xx[3];
+            a2 += v[8] * xx[0] + v[9] * xx[1] + v[10] * xx[2] + v[11] * xx[3];
+            a3 += v[12] * xx[0] + v[13] * xx[1] + v[14] * xx[2] + v[15] * xx[3];
+        }
+        y[4 * (int64_t)i] = a0; y[4 * (int64_t)i + 1] = a1; y[4 * (int64_t)i + 2] = a2; y[4 * (int64_t)i + 3] = a3;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 4x4 helpers
+ * ---------------------------------------------------------------------------------------------- */
+static void inv4(const double* A, double* Ai) {
+    double M[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { M[r][c] = A[4 * r + c]; M[r][4 + c] = (r == c); }
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int r = k + 1; r < 4; ++r) if (fabs(M[r][k]) > fabs(M[p][k])) p = r;
+        if (p != k) for (int c = 0; c < 8; ++c) { double t = M[k][c]; M[k][c] = M[p][c]; M[p][c] = t; }
+        const double ip = M[k][k] != 0.0 ? 1.0 / M[k][k] : 0.0;
+        for (int c = 0; c < 8; ++c) M[k][c] *= ip;
+        for (int r = 0; r < 4; ++r) if (r != k) { const double f = M[r][k]; for (int c = 0; c < 8; ++c) M[r][c] -= f * M[k][c]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ai[4 * r + c] = M[r][4 + c];
+}
+static inline void mm4(const double* A, const double* B, double* C) {           /* C = A B */
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+        double s = 0; for (int k = 0; k < 4; ++k) s += A[4 * r + k] * B[4 * k + c]; C[4 * r + c] = s; }
+}
+static inline void mv4_sub(const double* A, const double* x, double* y) {       /* y -= A x */
+    for (int r = 0; r < 4; ++r) y[r] -= A[4 * r] * x[0] + A[4 * r + 1] * x[1] + A[4 * r + 2] * x[2] + A[4 * r + 3] * x[3];
+}
+
+/* Preconditioner object: pc 0 none, 1 point-block Jacobi, 2 bjacobi(nblocks)+ILU(0) (PETSc's parallel default) */
+typedef struct {
+    int pc, nblocks;
+    int32_t n;
+    const int32_t *rowptr, *colind;
+    double* fact;      /* ILU factors in the BSR pattern (couplings across thread blocks dropped) */
+    double* dinv;      /* inverse diagonal blocks */
+    int32_t* diag;
+    int32_t* bstart;   /* nblocks+1 row offsets */
+} orc_pc;
+
+static void pc_free(orc_pc* P) { free(P->fact); free(P->dinv); free(P->diag); free(P->bstart); }
+
+static void pc_setup(orc_pc* P, int pc, int nblocks, int32_t n, const int32_t* rowptr, const int32_t* colind,
+                     const double* vals) {
+    memset(P, 0, sizeof(*P));
+    P->pc = pc; P->n = n; P->rowptr = rowptr; P->colind = colind;
+    P->nblocks = nblocks < 1 ? 1 : nblocks;
+    P->diag = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    P->dinv = (double*)malloc((size_t)n * 16 * sizeof(double));
+    for (int32_t i = 0; i < n; ++i) P->diag[i] = find_slot(rowptr, colind, i, i);
+    P->bstart = (int32_t*)malloc((size_t)(P->nblocks + 1) * sizeof(int32_t));
+    for (int b = 0; b <= P->nblocks; ++b) P->bstart[b] = (int32_t)(((int64_t)n * b) / P->nblocks);
+    if (pc == 1) {
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n; ++i) inv4(vals + 16 * (int64_t)P->diag[i], P->dinv + 16 * (int64_t)i);
+    } else if (pc == 2) {
+        const int64_t nnzb = rowptr[n];
+        P->fact = (double*)malloc((size_t)nnzb * 16 * sizeof(double));
+        memcpy(P->fact, vals, (size_t)nnzb * 16 * sizeof(double));
+#pragma omp parallel for schedule(static, 1)
+        for (int b = 0; b < P->nblocks; ++b) {
+            const int32_t r0 = P->bstart[b], r1 = P->bstart[b + 1];
+            for (int32_t i = r0; i < r1; ++i) {
+                for (int32_t s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+                    const int32_t k = colind[s];
+                    if (k < r0 || k >= i) continue;                       /* strictly lower, inside the block */
+                    double L[16];
+                    mm4(P->fact + 16 * (int64_t)s, P->dinv + 16 * (int64_t)k, L);   /* L_ik = A_ik U_kk^-1 */
+                    memcpy(P->fact + 16 * (int64_t)s, L, sizeof(L));
+                    for (int32_t q = P->diag[k] + 1; q < rowptr[k + 1]; ++q) {        /* U_kj, j > k */
+                        const int32_t j = colind[q];
+                        if (j >= r1) break;
+                        const int32_t dst = find_slot(rowptr, colind, i, j);
+                        if (dst < 0) continue;                                         /* ILU(0): no fill */
+                        double T[16];
+                        mm4(L, P->fact + 16 * (int64_t)q, T);
+                        double* D = P->fact + 16 * (int64_t)dst;
+                        for (int e = 0; e < 16; ++e) D[e] -= T[e];
+                    }
+                }
+                inv4(P->fact + 16 * (int64_t)P->diag[i], P->dinv + 16 * (int64_t)i);
+            }
+        }
+    }
+}
+
+static void pc_apply(const orc_pc* P, const double* r, double* z) {
+    const int32_t n = P->n;
+    if (P->pc == 0) { memcpy(z, r, (size_t)n * 4 * sizeof(double)); return; }
+    if (P->pc == 1) {
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n; ++i) {
+            const double* D = P->dinv + 16 * (int64_t)i; const double* rr = r + 4 * (int64_t)i; double* zz = z + 4 * (int64_t)i;
+            for (int c = 0; c < 4; ++c) zz[c] = D[4 * c] * rr[0] + D[4 * c + 1] * rr[1] + D[4 * c + 2] * rr[2] + D[4 * c + 3] * rr[3];
+        }
+        return;
+    }
+#pragma omp parallel for schedule(static, 1)
+    for (int b = 0; b < P->nblocks; ++b) {
+        const int32_t r0 = P->bstart[b], r1 = P->bstart[b + 1];
+        for (int32_t i = r0; i < r1; ++i) {                               /* forward: y = L^-1 r (unit lower) */
+            double y[4] = {r[4 * (int64_t)i], r[4 * (int64_t)i + 1], r[4 * (int64_t)i + 2], r[4 * (int64_t)i + 3]};
+            for (int32_t s = P->rowptr[i]; s < P->diag[i]; ++s) {
+                const int32_t k = P->colind[s];
+                if (k < r0) continue;
+                mv4_sub(P->fact + 16 * (int64_t)s, z + 4 * (int64_t)k, y);
+            }
+            memcpy(z + 4 * (int64_t)i, y, sizeof(y));
+        }
+        for (int32_t i = r1 - 1; i >= r0; --i) {                          /* backward: x = U^-1 y */
+            double y[4] = {z[4 * (int64_t)i], z[4 * (int64_t)i + 1], z[4 * (int64_t)i + 2], z[4 * (int64_t)i + 3]};
+            for (int32_t s = P->diag[i] + 1; s < P->rowptr[i + 1]; ++s) {
+                const int32_t j = P->colind[s];
+                if (j >= r1) break;
+                mv4_sub(P->fact + 16 * (int64_t)s, z + 4 * (int64_t)j, y);
+            }
+            const double* D = P->dinv + 16 * (int64_t)i;
+            double* zz = z + 4 * (int64_t)i;
+            for (int c = 0; c < 4; ++c) zz[c] = D[4 * c] * y[0] + D[4 * c + 1] * y[1] + D[4 * c + 2] * y[2] + D[4 * c + 3] * y[3];
+        }
+    }
+}
+
+static double dotp(int64_t n, const double* a, const double* b) {
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+/* KSPSolve: method 0 = BiCGStab (bcgs), 1 = TFQMR (tfqmr); right preconditioning; x holds the initial guess.
+ * reason: PETSc numbering (2 rtol, 3 atol, -3 its, -5 breakdown). */
+int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals, const double* b, double* x,
+              int method, int pc, int nblocks, double rtol, double atol, int maxit, int* its_out, int* reason_out,
+              double* rnorm_out) {
+    const int64_t N = 4 * (int64_t)n;
+    orc_pc P;
+    pc_setup(&P, pc, nblocks, n, rowptr, colind, vals);
+    double* buf = (double*)calloc((size_t)N * 10, sizeof(double));
+    double *r = buf, *rh = buf + N, *p = buf + 2 * N, *v = buf + 3 * N, *s = buf + 4 * N, *t = buf + 5 * N,
+           *ph = buf + 6 * N, *sh = buf + 7 * N, *w1 = buf + 8 * N, *w2 = buf + 9 * N;
+    orc_spmv(n, rowptr, colind, vals, x, r);
+    for (int64_t i = 0; i < N; ++i) r[i] = b[i] - r[i];
+    const double bn = sqrt(dotp(N, b, b));
+    double rn = sqrt(dotp(N, r, r));
+    const double tol = fmax(rtol * bn, atol);
+    int its = 0, reason = 0;
+    if (rn <= tol) reason = rn <= atol ? 3 : 2;
+    if (!reason && method == 0) {
+        memcpy(rh, r, (size_t)N * sizeof(double));
+        double rho = 1, alpha = 1, omega = 1;
+        for (its = 1; its <= maxit; ++its) {
+            const double rho_new = dotp(N, rh, r);
+            if (rho_new == 0.0) { reason = -5; break; }
+            const double beta = (rho_new / rho) * (alpha / omega);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+            pc_apply(&P, p, ph);
+            orc_spmv(n, rowptr, colind, vals, ph, v);
+            alpha = rho_new / dotp(N, rh, v);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) s[i] = r[i] - alpha * v[i];
+            pc_apply(&P, s, sh);
+            orc_spmv(n, rowptr, colind, vals, sh, t);
+            const double tt = dotp(N, t, t);
+            omega = tt > 0 ? dotp(N, t, s) / tt : 0.0;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) { x[i] += alpha * ph[i] + omega * sh[i]; r[i] = s[i] - omega * t[i]; }
+            rho = rho_new;
+            rn = sqrt(dotp(N, r, r));
+            if (!(rn == rn)) { reason = -9; break; }
+            if (rn <= tol) { reason = rn <= atol ? 3 : 2; break; }
+            if (omega == 0.0) { reason = -5; break; }
+        }
+        if (!reason) { reason = -3; its = maxit; }
+    } else if (!reason) {
+        /* TFQMR (Freund 1993) on B = A M^-1;  xhat accumulates in the preconditioned space */
+        double *w = w1, *y1 = p, *y2 = s, *u1 = v, *u2 = t, *d = ph, *vv = sh, *xh = w2, *rt = rh;
+        memcpy(w, r, (size_t)N * sizeof(double));
+        memcpy(y1, r, (size_t)N * sizeof(double));
+        memcpy(rt, r, (size_t)N * sizeof(double));
+        double* tmp = (double*)malloc((size_t)N * sizeof(double));
+        pc_apply(&P, y1, tmp); orc_spmv(n, rowptr, colind, vals, tmp, vv);
+        memcpy(u1, vv, (size_t)N * sizeof(double));
+        memset(d, 0, (size_t)N * sizeof(double));
+        memset(xh, 0, (size_t)N * sizeof(double));
+        double tau = rn, theta = 0.0, eta = 0.0, rho = dotp(N, rt, r);
+        int done = 0;
+        for (its = 1; its <= maxit && !done; ++its) {
+            const double sigma = dotp(N, rt, vv);
+            if (sigma == 0.0 || rho == 0.0) { reason = -5; break; }
+            const double alpha = rho / sigma;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) y2[i] = y1[i] - alpha * vv[i];
+            pc_apply(&P, y2, tmp); orc_spmv(n, rowptr, colind, vals, tmp, u2);
+            for (int m = 0; m < 2; ++m) {
+                const double* um = m == 0 ? u1 : u2;
+                const double* ym = m == 0 ? y1 : y2;
+                const double coef = theta * theta * eta / alpha;
+#pragma omp parallel for schedule(static)
+                for (int64_t i = 0; i < N; ++i) { w[i] -= alpha * um[i]; d[i] = ym[i] + coef * d[i]; }
+                theta = sqrt(dotp(N, w, w)) / tau;
+                const double c = 1.0 / sqrt(1.0 + theta * theta);
+                tau = tau * theta * c;
+                eta = c * c * alpha;
+#pragma omp parallel for schedule(static)
+                for (int64_t i = 0; i < N; ++i) xh[i] += eta * d[i];
+                rn = tau * sqrt((double)(2 * its - 1 + m) + 1.0);          /* residual bound */
+                if (rn <= tol) { done = 1; break; }
+            }
+            if (done) break;
+            const double rho_new = dotp(N, rt, w);
+            const double beta = rho_new / rho;
+            rho = rho_new;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) y1[i] = w[i] + beta * y2[i];
+            pc_apply(&P, y1, tmp); orc_spmv(n, rowptr, colind, vals, tmp, u1);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < N; ++i) vv[i] = u1[i] + beta * (u2[i] + beta * vv[i]);
+        }
+        pc_apply(&P, xh, tmp);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < N; ++i) x[i] += tmp[i];
+        /* true residual decides */
+        orc_spmv(n, rowptr, colind, vals, x, tmp);
+        double s2 = 0.0;
+        for (int64_t i = 0; i < N; ++i) { const double e = b[i] - tmp[i]; s2 += e * e; }
+        rn = sqrt(s2);
+        if (!reason) reason = done ? (rn <= 10.0 * tol ? 2 : -3) : -3;
+        if (its > maxit) its = maxit;
+        free(tmp);
+    }
+    *its_out = its; *reason_out = reason; *rnorm_out = rn;
+    free(buf);
+    pc_free(&P);
+    return 0;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -42,10 +42,10 @@ class SnsTimings(C.Structure):
 
 # constants of sns.h
 FORM_STOKES, FORM_NS = 0, 1
-KSP_BICGSTAB, KSP_FGMRES = 0, 1
+KSP_BICGSTAB, KSP_FGMRES, KSP_TFQMR = 0, 1, 2
 PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2
 EXPORT_ROWPTR, EXPORT_COLIND, EXPORT_VALS, EXPORT_KE, EXPORT_FE = 0, 1, 2, 3, 4
-KSP_NAMES = {"bicgstab": KSP_BICGSTAB, "bcgs": KSP_BICGSTAB, "fgmres": KSP_FGMRES, "gmres": KSP_FGMRES}
+KSP_NAMES = {"bicgstab": KSP_BICGSTAB, "bcgs": KSP_BICGSTAB, "fgmres": KSP_FGMRES, "gmres": KSP_FGMRES, "tfqmr": KSP_TFQMR}
 PC_NAMES = {"none": PC_NONE, "bjacobi": PC_BJACOBI, "jacobi": PC_BJACOBI, "amg": PC_AMG}
 
 # every symbol include/sns.h declares: (name, restype, argtypes)

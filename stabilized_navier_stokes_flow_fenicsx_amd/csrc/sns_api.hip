@@ -732,6 +732,94 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
     return SNS_OK;
 }
 
+// ---- TFQMR (Freund 1993) on B = A M^-1: the reference's KSP type ('tfqmr', :77, :199, :282) ----
+// Same recurrences as oracle/c/sns_oracle.c:orc_solve(method=1).  The quasi-residual bound
+// tau*sqrt(m+1) drives the stopping test (as in PETSc); the true residual is reported at the end.
+int tfqmr(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
+    const sns_options& o = h->opt;
+    const int64_t nd = nred_of(h);
+    const int g = vec_grid(nd);
+    double *w, *y1, *y2, *u1, *u2, *d, *v, *xh, *rt, *tmp;
+    SNS_TRY(get_vec(h, 0, &w)); SNS_TRY(get_vec(h, 1, &y1)); SNS_TRY(get_vec(h, 2, &y2)); SNS_TRY(get_vec(h, 3, &u1));
+    SNS_TRY(get_vec(h, 4, &u2)); SNS_TRY(get_vec(h, 5, &d)); SNS_TRY(get_vec(h, 6, &v)); SNS_TRY(get_vec(h, 7, &xh));
+    SNS_TRY(get_vec(h, 8, &rt)); SNS_TRY(get_vec(h, 9, &tmp));
+    auto axpby = [&](double a, const double* xx, double bb, double* yy) {
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, h->stream, nd, a, xx, bb, yy);
+    };
+    auto lin3 = [&](double a, const double* xx, double bb, const double* yy, double c, double* zz) {
+        hipLaunchKernelGGL(k_axpbypcz, dim3(g), dim3(256), 0, h->stream, nd, a, xx, bb, yy, c, zz);
+    };
+    auto applyB = [&](const double* in, double* out) -> int {
+        SNS_TRY(pc_apply(h, in, tmp));
+        return op_apply(h, tmp, out);
+    };
+    double bnorm, rn;
+    SNS_TRY(norm2(h, b, &bnorm));
+    SNS_TRY(op_residual(h, x, b, w));
+    SNS_TRY(norm2(h, w, &rn));
+    const double tol = std::max(o.ksp_rtol * bnorm, o.ksp_atol);
+    if (o.monitor) std::printf("  0 KSP Residual norm %.12e\n", rn);
+    int its = 0, reason = 0;
+    if (!(rn == rn)) reason = SNS_KSP_DIVERGED_NANORINF;
+    else if (rn <= tol) reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL;
+    if (!reason) {
+        HIP_TRY(hipMemcpyAsync(y1, w, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(rt, w, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        SNS_TRY(applyB(y1, v));
+        HIP_TRY(hipMemcpyAsync(u1, v, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(d, 0, nd * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(xh, 0, nd * sizeof(double), h->stream));
+        double tau = rn, theta = 0.0, eta = 0.0, rho = rn * rn;
+        bool done = false;
+        for (its = 1; its <= o.ksp_max_it && !done; ++its) {
+            double sigma;
+            SNS_TRY(dot(h, rt, v, &sigma));
+            if (sigma == 0.0 || rho == 0.0) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+            const double alpha = rho / sigma;
+            lin3(1.0, y1, -alpha, v, 0.0, y2);
+            SNS_TRY(applyB(y2, u2));
+            for (int m = 0; m < 2; ++m) {
+                const double* um = m == 0 ? u1 : u2;
+                const double* ym = m == 0 ? y1 : y2;
+                axpby(-alpha, um, 1.0, w);
+                axpby(1.0, ym, theta * theta * eta / alpha, d);
+                double wn;
+                SNS_TRY(norm2(h, w, &wn));
+                theta = wn / tau;
+                const double c = 1.0 / std::sqrt(1.0 + theta * theta);
+                tau = tau * theta * c;
+                eta = c * c * alpha;
+                axpby(eta, d, 1.0, xh);
+                rn = tau * std::sqrt((double)(2 * its - 1 + m) + 1.0);
+                if (o.monitor) std::printf("%3d.%d KSP Residual bound %.12e\n", its, m, rn);
+                if (!(rn == rn)) { reason = SNS_KSP_DIVERGED_NANORINF; done = true; break; }
+                if (rn <= tol) { done = true; break; }
+            }
+            if (done) break;
+            double rho_new;
+            SNS_TRY(dot(h, rt, w, &rho_new));
+            const double beta = rho_new / rho;
+            rho = rho_new;
+            lin3(1.0, w, beta, y2, 0.0, y1);
+            SNS_TRY(applyB(y1, u1));
+            lin3(1.0, u1, beta, u2, beta * beta, v);
+        }
+        if (its > o.ksp_max_it) its = o.ksp_max_it;
+        SNS_TRY(pc_apply(h, xh, tmp));
+        axpby(1.0, tmp, 1.0, x);
+        SNS_TRY(op_residual(h, x, b, w));
+        SNS_TRY(norm2(h, w, &rn));
+        if (!reason) {
+            if (done && rn <= 10.0 * tol) reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL;
+            else reason = SNS_KSP_DIVERGED_ITS;
+        }
+    }
+    *its_out = its;
+    *reason_out = reason;
+    *rnorm_out = rn;
+    return SNS_OK;
+}
+
 // ---- FGMRES(m), right preconditioning, classical Gram-Schmidt with one re-orthogonalisation ----
 int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
     const sns_options& o = h->opt;
@@ -860,6 +948,7 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     int rc;
     if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
     else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
+    else if (h->opt.ksp_type == SNS_KSP_TFQMR) rc = tfqmr(h, b, x, its, reason, rnorm);
     else { set_error("bad ksp_type"); return SNS_E_ARG; }
     SNS_TRY(rc);
     SNS_TRY(halo_exchange(h, x));                          // leave the solution's ghost tail current

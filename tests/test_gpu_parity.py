@@ -140,7 +140,8 @@ def test_block_jacobi_and_amg_are_linear_and_match_oracle_inverse(gpu):
     P.close()
 
 
-@pytest.mark.parametrize("ksp,pc", [("fgmres", "amg"), ("bicgstab", "amg"), ("bicgstab", "bjacobi"), ("fgmres", "bjacobi")])
+@pytest.mark.parametrize("ksp,pc", [("fgmres", "amg"), ("bicgstab", "amg"), ("tfqmr", "amg"), ("bicgstab", "bjacobi"),
+                                    ("fgmres", "bjacobi"), ("tfqmr", "bjacobi")])
 def test_stokes_solve_vs_lu(gpu, ksp, pc):
     from oracle import solve as S
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
