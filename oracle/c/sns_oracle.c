@@ -541,6 +541,14 @@ int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const dou
     return 0;
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -31,6 +31,10 @@ def num_threads() -> int:
     return load().orc_num_threads()
 
 
+def set_num_threads(n: int):
+    load().orc_set_num_threads(C.c_int(int(n)))
+
+
 def ns_elements(X, W, Re):
     lib = load()
     X = np.ascontiguousarray(X, np.float64); W = np.ascontiguousarray(W, np.float64).reshape(len(X), 16)
