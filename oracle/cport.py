@@ -14,7 +14,8 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        src = os.path.join(_HERE, "c", "sns_oracle.c")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
             import subprocess
             subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")])
         _lib = C.CDLL(LIB)
