@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(sample_cells=(140, 35, 35), re_full=200.0, full_ny=75):
+def cpu_baseline(sample_cells=(200, 50, 50), re_full=200.0, full_ny=75):
     """The oracle's C/OpenMP restatement ("port", oracle/c) timed on the host cores on a bounded
     sample of the same workload: ONE Newton iteration (assemble J+F, solve to rtol 1e-8) on the
-    ~1 M-tet duct at the same cell Reynolds number Re*h as the full run, with the REFERENCE's
+    3 M-tet duct at the same cell Reynolds number Re*h as the full run, with the REFERENCE's
     linear algorithm: KSP tfqmr (NavierStokesChannelFlow.py:77,282-283) + PETSc's default
     preconditioner, block-Jacobi (one block per thread) with ILU(0) on each block."""
     from oracle import cport
