@@ -161,19 +161,22 @@ def main():
     tm = P.timings()
     kt = P.kernel_times()
     s = P.sizes()
-    # dominant kernel: the level-0 block-Jacobi sweep k_spmv<SPMV_JACOBI, FINE> (3 of the 5 fine-level
-    # matrix passes per FGMRES iteration).  Algorithmic bytes per launch:
-    #   132 B per nonzero block (128 values + 4 column index) + per block row 4 rowptr + 32 x + 32 b
-    #   + 128 Dinv + 32 y  = 132*nnzb + 228*n_rows
+    # dominant kernel: the level-0 block-Jacobi sweep of the AMG cycle (3 of the 5 fine-level matrix passes
+    # per preconditioner application).  Algorithmic bytes per launch:
+    #   per nonzero block: values (64 B as the preconditioner's fp32 copy, 128 B in fp64) + 4 B column index
+    #   per block row: 4 rowptr + 32 x + 32 b + 128 Dinv + 32 y = 228 B
+    f32 = bool(P.options.amg_f32_matrix)
+    kname = "k_spmv_f32<SPMV_JACOBI,FINE>" if f32 else "k_spmv<SPMV_JACOBI,FINE>"
     jac_ms, jac_calls = kt["jacobi"]
-    alg_bytes = 132.0 * s["nnzb"] + 228.0 * s["n_owned"]
+    alg_bytes = (68.0 if f32 else 132.0) * s["nnzb"] + 228.0 * s["n_owned"]
     roofline = None
     if jac_calls > 0:
         avg_ms = jac_ms / jac_calls
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                    "kernel": "k_spmv<SPMV_JACOBI,FINE>", "avg_launch_ms": round(avg_ms, 5),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic("k_spmv_f32<2, 1>" if f32 else "k_spmv<2, 1>"),
+                    "kernel": kname, "avg_launch_ms": round(avg_ms, 5),
                     "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
                     "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}
                                         for k, v in kt.items() if v[1] > 0 and k != "jacobi"}}
@@ -182,6 +185,9 @@ def main():
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "precision_note": "operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "
+                          "smoother/residual passes read an fp32 copy of the level matrices (arithmetic f64)"
+                          if P.options.amg_f32_matrix else "all f64",
         "config": {"workload": f"duct {cells[0]}x{cells[1]}x{cells[2]} cells = {mesh.num_tets} tets, "
                                f"{n_dof_global} dofs, Re={args.re:g}, Newton iteration (assemble J+F, AMG setup, "
                                f"{args.ksp} rtol 1e-8, bt line search)",

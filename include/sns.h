@@ -90,6 +90,8 @@ typedef struct {
     double amg_omega;       /* block-Jacobi damping (0.8)                            */
     int    monitor;         /* 1: print ||r|| per Krylov/Newton iteration (ksp_monitor / snes_monitor :201,:276) */
     int    corrected_convection; /* 0 = reference as written (dot(u,grad(.)) :241,:247); 1 = (u.grad)(.) */
+    int    amg_f32_matrix;  /* 1: the AMG smoother/residual passes read an fp32 copy of each level
+                               operator (vectors and arithmetic stay fp64; the Krylov operator stays fp64) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

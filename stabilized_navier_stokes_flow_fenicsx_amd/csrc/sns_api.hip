@@ -213,6 +213,27 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
     }
 }
 
+// Preconditioner passes (Jacobi sweep, residual) of the AMG cycle: fp32 matrix copy when enabled.
+template <int MODE>
+void launch_pc_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
+                    double omega) {
+    if (!(h->opt.amg_f32_matrix && L.vals32)) {
+        launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr);
+        return;
+    }
+    const int grid = (rows + 63) / 64;
+    if (grid == 0) return;
+    if (&L == &h->levels[0]) {
+        time_begin(h, MODE);
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
+                           L.vals32, x, y, b, L.dinv, omega);
+        time_end(h);
+    } else {
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
+                           L.vals32, x, y, b, L.dinv, omega);
+    }
+}
+
 int alloc_level_vectors(Level& L) {
     const size_t nd = 4 * (size_t)L.n;
     SNS_TRY(dev_alloc(&L.x, nd));
@@ -481,6 +502,11 @@ int pc_setup(sns_ctx* h) {
         const int32_t rows = L.n_owned;
         hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
+        if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
+            if (!L.vals32) SNS_TRY(dev_alloc(&L.vals32, (size_t)L.nnzb * 16));
+            hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.nnzb * 16)), dim3(256), 0, h->stream, L.nnzb * 16, L.vals,
+                               L.vals32);
+        }
         if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             double lam = 0.0;
             SNS_TRY(estimate_lambda_max(h, l, &lam));
@@ -557,7 +583,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         double* oth = h->pong[l];
         hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
         for (int s = 0; s < 8; ++s) {       // even count: result ends in x
-            launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+            launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
             std::swap(cur, oth);
         }
         return SNS_OK;
@@ -568,15 +594,15 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     double* oth = (nswaps & 1) ? x : h->pong[l];
     if (rows > 0) hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
     for (int s = 1; s < nu; ++s) {
-        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
     if (L.xg) {      // distributed: true residual needs the neighbours' iterate; smoothing itself stays rank-local
         HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         SNS_TRY(exchange_level(h, l, L.xg));
-        launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0, nullptr);
+        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
     } else {
-        launch_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, nullptr);
+        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     }
     Level& C = h->levels[l + 1];
     if (C.n_owned > 0)
@@ -585,7 +611,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     SNS_TRY(vcycle(h, l + 1, C.b, C.x));
     if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     for (int s = 0; s < nu; ++s) {
-        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om, nullptr);
+        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
     // cur == x by construction of the start buffer
@@ -830,16 +856,17 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
         if (h->gm_V) { (void)hipFree(h->gm_V); (void)hipFree(h->gm_Z); (void)hipFree(h->d_h); }
         SNS_TRY(dev_alloc(&h->gm_V, (size_t)(m + 1) * ld));
         SNS_TRY(dev_alloc(&h->gm_Z, (size_t)m * ld));
-        SNS_TRY(dev_alloc(&h->d_h, (size_t)3 * (m + 8)));
+        SNS_TRY(dev_alloc(&h->d_h, (size_t)2 * (m + 16)));
         HIP_TRY(hipMemset(h->gm_V, 0, (size_t)(m + 1) * ld * sizeof(double)));
         HIP_TRY(hipMemset(h->gm_Z, 0, (size_t)m * ld * sizeof(double)));
         h->gm_m = m;
     }
     double* V = h->gm_V;
     double* Z = h->gm_Z;
-    double* dh1 = h->d_h;                 // pass-1 coefficients [m+8]
-    double* dh2 = h->d_h + (m + 8);       // pass-2 coefficients, then ||w||^2 at [m+8 - 1 .. ]
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1), y(m), hcol(2 * (m + 8) + 1);
+    const int S = m + 16;                 // stride of one coefficient block
+    double* dh1 = h->d_h;                 // pass-1 coefficients [0, m+8)
+    double* dh2 = h->d_h + S;             // pass-2 coefficients [0, m+8), then (w.w, w.w) at [m+8, m+10)
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1), y(m), hcol(2 * (m + 16));
     double bnorm, rn;
     SNS_TRY(norm2(h, b, &bnorm));
     const double tol = std::max(o.ksp_rtol * bnorm, o.ksp_atol);
@@ -876,8 +903,8 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
                 }
                 if (pass == 1) {
                     hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, w, w, h->partial);
-                    reduce_local(h, g, 1, dh + (m + 7));          // last slot of the pass-2 block: w.w
-                    SNS_TRY(allreduce(h, dh, m + 8));
+                    reduce_local(h, g, 2, dh + (m + 8));          // k_dot2 emits (x.y, y.y): both are w.w here
+                    SNS_TRY(allreduce(h, dh, m + 10));
                 } else {
                     SNS_TRY(allreduce(h, dh, nv));
                 }
@@ -888,14 +915,14 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
                 }
             }
             // one device->host transfer per iteration: h1[0..nv), h2[0..nv), w.w
-            SNS_TRY(fetch(h, h->d_h, 2 * (m + 8), hcol.data()));
+            SNS_TRY(fetch(h, h->d_h, 2 * S, hcol.data()));
             double* Hj = &H[(size_t)j * (m + 1)];             // column j
             double h2sq = 0.0;
             for (int k = 0; k < nv; ++k) {
-                Hj[k] = hcol[k] + hcol[(m + 8) + k];
-                h2sq += hcol[(m + 8) + k] * hcol[(m + 8) + k];
+                Hj[k] = hcol[k] + hcol[S + k];
+                h2sq += hcol[S + k] * hcol[S + k];
             }
-            const double ww = hcol[(m + 8) + (m + 7)];
+            const double ww = hcol[S + (m + 8)];
             double wn2 = ww - h2sq;
             double wn;
             if (!(wn2 > 1e-6 * ww)) SNS_TRY(norm2(h, w, &wn));   // heavy cancellation: measure it
@@ -1000,6 +1027,7 @@ void sns_default_options(sns_options* o) {
     o->amg_omega = 0.8;
     o->monitor = 0;
     o->corrected_convection = 0;
+    o->amg_f32_matrix = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1109,7 +1137,7 @@ int sns_destroy(sns_handle h) {
     fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
-        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv);
+        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);

@@ -51,6 +51,7 @@ struct Level {
     int32_t *rowptr = nullptr, *colind = nullptr, *diag = nullptr;
     double* vals = nullptr;              // nnzb*16, block row-major
     double* dinv = nullptr;              // n*16
+    float* vals32 = nullptr;             // fp32 copy of vals for the preconditioner passes (amg_f32_matrix)
     // to the next coarser level
     int32_t nc = 0;
     int32_t* agg = nullptr;              // n

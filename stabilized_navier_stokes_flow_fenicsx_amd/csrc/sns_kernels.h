@@ -25,6 +25,10 @@ template <int MODE, int FINE>
 __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial);
+template <int MODE, int FINE>
+__global__ void k_spmv_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const float* vals,
+                           const double* x, double* y, const double* bvec, const double* dinv, double omega);
+__global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
 __global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);

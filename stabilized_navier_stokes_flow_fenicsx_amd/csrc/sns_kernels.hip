@@ -443,6 +443,15 @@ __global__ __launch_bounds__(256) void k_gather_residual(int32_t n_rows, const i
 // Workgroups are remapped so that each XCD walks one contiguous eighth of the
 // matrix (its private L2 then holds the x entries of ITS rows only).
 // ============================================================================
+// quad-permute a double with DPP moves (no LDS, no memory traffic); CTRL = quad_perm encoding
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
     const int q = nb >> 3, r = nb & 7;
     const int xcd = b & 7, k = b >> 3;
@@ -466,28 +475,28 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
     const int32_t row = (blk * 4 + (tid >> 6)) * 8 + (lane >> 3);
     double acc0 = 0.0, acc1 = 0.0;
     const bool live = row < n_rows;
-    if (live) {
-        const int32_t s = rowptr[row], e = rowptr[row + 1];
+    {
+        // the 8 lanes of a row share the trip count, so each quad is uniform: lane j of a quad fetches
+        // component j of the x block (8 B) and the pair (2*hf, 2*hf+1) it needs arrives by DPP
+        const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+        const int jq = lane & 3;
         const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals) + ((int64_t)s * 8 + r * 2 + hf);
         int32_t k = s;
         for (; k + 3 < e; k += 4) {
             const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
             const double2 a0 = vp[0], a1 = vp[8], a2 = vp[16], a3 = vp[24];
-            const double2 x0 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c0 + 2 * hf);
-            const double2 x1 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c1 + 2 * hf);
-            const double2 x2 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c2 + 2 * hf);
-            const double2 x3 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c3 + 2 * hf);
-            acc0 += a0.x * x0.x + a0.y * x0.y;
-            acc1 += a1.x * x1.x + a1.y * x1.y;
-            acc0 += a2.x * x2.x + a2.y * x2.y;
-            acc1 += a3.x * x3.x + a3.y * x3.y;
+            const double g0 = x[4 * (int64_t)c0 + jq], g1 = x[4 * (int64_t)c1 + jq];
+            const double g2 = x[4 * (int64_t)c2 + jq], g3 = x[4 * (int64_t)c3 + jq];
+            acc0 += a0.x * quad_perm<0x88>(g0) + a0.y * quad_perm<0xDD>(g0);
+            acc1 += a1.x * quad_perm<0x88>(g1) + a1.y * quad_perm<0xDD>(g1);
+            acc0 += a2.x * quad_perm<0x88>(g2) + a2.y * quad_perm<0xDD>(g2);
+            acc1 += a3.x * quad_perm<0x88>(g3) + a3.y * quad_perm<0xDD>(g3);
             vp += 32;
         }
         for (; k < e; ++k) {
-            const int32_t c0 = colind[k];
             const double2 a0 = vp[0];
-            const double2 x0 = *reinterpret_cast<const double2*>(x + 4 * (int64_t)c0 + 2 * hf);
-            acc0 += a0.x * x0.x + a0.y * x0.y;
+            const double g0 = x[4 * (int64_t)colind[k] + jq];
+            acc0 += a0.x * quad_perm<0x88>(g0) + a0.y * quad_perm<0xDD>(g0);
             vp += 8;
         }
     }
@@ -535,6 +544,81 @@ SNS_INST_SPMV(SPMV_AX_DOT, 1)
 SNS_INST_SPMV(SPMV_AX, 0)
 SNS_INST_SPMV(SPMV_B_MINUS_AX, 0)
 SNS_INST_SPMV(SPMV_JACOBI, 0)
+
+// Preconditioner passes with fp32 MATRIX VALUES (vectors, D^-1 and all arithmetic stay fp64):
+// the smoother / residual passes of the AMG cycle read a rounded copy of each level operator,
+// 68 B instead of 132 B per block.  4 lanes per block row: lane r loads the whole row r of a block
+// as one float4 (16 B) -> 16 block rows per wave, no cross-lane reduction.
+// broadcast lane J of every quad (4 consecutive lanes)
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) { return quad_perm<J * 0x55>(v); }
+
+template <int MODE, int FINE>
+__global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ colind,
+                                                  const float* __restrict__ vals, const double* __restrict__ x,
+                                                  double* __restrict__ y, const double* __restrict__ bvec,
+                                                  const double* __restrict__ dinv, double omega) {
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 3;
+    const int32_t row = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool live = row < n_rows;
+    double acc0 = 0.0, acc1 = 0.0;
+    // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
+    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
+    int32_t k = s;
+    for (; k + 3 < e; k += 4) {
+        const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
+        const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
+        // lane r fetches component r of each x block (8 B); the quad shares them through DPP
+        const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
+        const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
+        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                (double)a0.w * quad_bcast<3>(g0);
+        acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
+                (double)a1.w * quad_bcast<3>(g1);
+        acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
+                (double)a2.w * quad_bcast<3>(g2);
+        acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
+                (double)a3.w * quad_bcast<3>(g3);
+        vp += 16;
+    }
+    for (; k < e; ++k) {
+        const float4 a0 = vp[0];
+        const double g0 = x[4 * (int64_t)colind[k] + r];
+        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                (double)a0.w * quad_bcast<3>(g0);
+        vp += 4;
+    }
+    const double acc = acc0 + acc1;                 // (A x)[4*row + r]
+    if (MODE == SPMV_B_MINUS_AX) {
+        if (live) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
+    } else if (MODE == SPMV_JACOBI) {
+        const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
+        const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
+        if (live) {
+            const double* D = dinv + 16 * (int64_t)row + 4 * r;
+            y[4 * (int64_t)row + r] =
+                x[4 * (int64_t)row + r] + omega * (D[0] * r0 + D[1] * r1 + D[2] * r2 + D[3] * r3);
+        }
+    }
+}
+template __global__ void k_spmv_f32<SPMV_B_MINUS_AX, 1>(int32_t, const int32_t*, const int32_t*, const float*,
+                                                        const double*, double*, const double*, const double*, double);
+template __global__ void k_spmv_f32<SPMV_JACOBI, 1>(int32_t, const int32_t*, const int32_t*, const float*,
+                                                    const double*, double*, const double*, const double*, double);
+template __global__ void k_spmv_f32<SPMV_B_MINUS_AX, 0>(int32_t, const int32_t*, const int32_t*, const float*,
+                                                        const double*, double*, const double*, const double*, double);
+template __global__ void k_spmv_f32<SPMV_JACOBI, 0>(int32_t, const int32_t*, const int32_t*, const float*,
+                                                    const double*, double*, const double*, const double*, double);
+
+__global__ __launch_bounds__(256) void k_cvt_f32(int64_t n, const double* __restrict__ x, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (float)x[i];
+}
 
 // ============================================================================
 // K3: 4x4 diagonal-block inverse (Gauss-Jordan, partial pivoting), one thread per node
