@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(sample_cells=(200, 50, 50), re_full=200.0, full_ny=75):
+def cpu_baseline(sample_cells=(140, 35, 35), re_full=200.0, full_ny=75):
     """The oracle's C/OpenMP restatement ("port", oracle/c) timed on the host cores on a bounded
     sample of the same workload: ONE Newton iteration (assemble J+F, solve to rtol 1e-8) on the
-    3 M-tet duct at the same cell Reynolds number Re*h as the full run, with the REFERENCE's
+    ~1 M-tet duct at the same cell Reynolds number Re*h as the full run, with the REFERENCE's
     linear algorithm: KSP tfqmr (NavierStokesChannelFlow.py:77,282-283) + PETSc's default
     preconditioner, block-Jacobi (one block per thread) with ILU(0) on each block."""
     from oracle import cport
@@ -42,9 +42,11 @@ def cpu_baseline(sample_cells=(200, 50, 50), re_full=200.0, full_ny=75):
     # one GPU's host share is 16 cores on the bench box; the reference's own runs use 6 ranks (run_all_images.sh:6)
     cport.set_num_threads(min(16, os.cpu_count() or 1, cport.num_threads()))
     nthr = cport.num_threads()
+    print(f"[bench] cpu_baseline: {m.num_tets} tets on {nthr} threads", file=sys.stderr, flush=True)
     rp, ci = cport.pattern(m.num_nodes, m.tets)
     vals, F0 = cport.assemble("stokes", m.points, m.tets, None, 1.0, mask, g, rp, ci)
-    U, sits, sreason, _ = cport.solve(m.num_nodes, rp, ci, vals, -F0, method="tfqmr", pc="ilu0", rtol=1e-8)
+    U, sits, sreason, _ = cport.solve(m.num_nodes, rp, ci, vals, -F0, method="tfqmr", pc="ilu0", rtol=1e-8, maxit=2000)
+    print(f"[bench] cpu_baseline: Stokes presolve {sits} its reason {sreason}", file=sys.stderr, flush=True)
     t0 = time.time()
     vals, F = cport.assemble("ns", m.points, m.tets, U, Re, mask, g, rp, ci)
     t1 = time.time()
