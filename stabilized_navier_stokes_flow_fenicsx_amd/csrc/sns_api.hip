@@ -86,6 +86,7 @@ struct sns_ctx {
     int* d_piv = nullptr;
     int* d_sing = nullptr;
     bool has_matrix = false, pc_ready = false;
+    int pc_setups = 0;
     int matrix_form = -1;
     // reductions
     double* partial = nullptr;                   // [2048*8]
@@ -508,8 +509,9 @@ int pc_setup(sns_ctx* h) {
                                L.vals32);
         }
         if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
-            double lam = 0.0;
-            SNS_TRY(estimate_lambda_max(h, l, &lam));
+            // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
+            double lam = L.lambda_max;
+            if (!(lam > 0.0) || (h->pc_setups & 3) == 0) SNS_TRY(estimate_lambda_max(h, l, &lam));
             L.lambda_max = lam;
             if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, 1.5 / lam);
             if (h->opt.monitor) std::printf("    AMG level %d: n %d |lambda|max(Dinv A) %.4f omega %.4f\n", l, rows, lam, L.omega);
@@ -543,6 +545,7 @@ int pc_setup(sns_ctx* h) {
                                h->d_sing);
         }
     }
+    ++h->pc_setups;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float ms = 0;

@@ -168,9 +168,38 @@ def save_navier_stokes_solution(u, p, msh, FolderName, Re):
 # --------------------------------------------------------------------------- #
 # drivers
 # --------------------------------------------------------------------------- #
+def _init_distributed():
+    """Under ``torchrun`` / ``torch.distributed.run`` (the counterpart of the reference's
+    ``mpirun -n 6``, run_all_images.sh:6): one rank per GPU over RCCL."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{lr}"))
+    return world
+
+
 def _problem(msh, bcs, **opt):
+    """One FlowProblem per rank: element-partitioned when launched on several GPUs."""
+    import torch
     from .solver import FlowProblem
+    if _init_distributed() > 1:
+        opt.pop("device", None)
+        return FlowProblem.distributed(msh, bcs, device=f"cuda:{torch.cuda.current_device()}", **opt)
     return FlowProblem(msh, bcs, **opt)
+
+
+def _to_global_host(P, x):
+    """Global nodal vector on the host (identical on every rank)."""
+    return (P.gather(x) if getattr(P, "part", None) is not None else x).cpu().numpy()
+
+
+def _from_global_host(P, xg):
+    import torch
+    return P.scatter(xg) if getattr(P, "part", None) is not None else torch.from_numpy(np.ascontiguousarray(xg)).to(P.device)
 
 
 def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
@@ -192,7 +221,7 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     if rank == 0:
         print("Interpolating Stokes Flow", flush=True)
     w_coarse, u, p = solve_navier_stokes(P, U_stokes.clone(), rank)
-    w_coarse_host = w_coarse.cpu().numpy()
+    w_coarse_host = _to_global_host(P, w_coarse)
     P.close()
     # Solve Navier Stokes With User Defined Mesh
     msh_f = generate_mesh(img_fname, channel_mesh_size)
@@ -201,8 +230,9 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     if rank == 0:
         print("Interpolating Coarse NS Flow", flush=True)
     w0 = interpolate_initial_guess(msh, w_coarse_host, msh_f)
-    w, u, p = solve_navier_stokes(Pf, torch.from_numpy(w0).to(Pf.device), rank)
-    out = dict(msh=msh_f, w=w.cpu().numpy(), u=u.cpu().numpy(), p=p.cpu().numpy(), Re=Re, img_fname=img_fname,
+    w, u, p = solve_navier_stokes(Pf, _from_global_host(Pf, w0), rank)
+    wg = _to_global_host(Pf, w)
+    out = dict(msh=msh_f, w=wg, u=wg.reshape(-1, 4)[:, :3].copy(), p=wg.reshape(-1, 4)[:, 3].copy(), Re=Re, img_fname=img_fname,
                channel_mesh_size=channel_mesh_size, flowrate_ratio=flowrate_ratio, newton=Pf.last_newton)
     Pf.close()
     return out
@@ -233,9 +263,10 @@ def stokes_channel_main(argv=None):
     print("\nStart Assembling Stiffness Matrix and Forcing Vector", flush=True)
     U, res = P.stokes_solve()
     print(f"Solve finished: {res.its} iterations, reason {res.reason}, {time.perf_counter() - t0:.2f} s", flush=True)
-    W = U.cpu().numpy().reshape(-1, 4)
-    write_xdmf("StokesChannelPressure", msh, "Pressure", W[:, 3])
-    write_xdmf("StokesChannelVelocity", msh, "Velocity", W[:, :3])
+    W = _to_global_host(P, U).reshape(-1, 4)
+    if _rank() == 0:
+        write_xdmf("StokesChannelPressure", msh, "Pressure", W[:, 3])
+        write_xdmf("StokesChannelVelocity", msh, "Velocity", W[:, :3])
     P.close()
     return msh, W
 
@@ -251,14 +282,15 @@ def duct_stokes_main(argv=None):
     M.write_msh2(msh, f"{gmsh_fname}.msh")                        # gmsh.write(f'{gmsh_fname}.msh') :141
     P = _problem(msh, B.duct_bcs(msh))
     U, res = P.stokes_solve()
-    W = U.cpu().numpy().reshape(-1, 4)
+    W = _to_global_host(P, U).reshape(-1, 4)
     u, p = W[:, :3], W[:, 3]
-    print(f"L1 norm of velocity coefficient vector: {np.linalg.norm(u.ravel())}")
-    print(f"L1 norm of pressure coefficient vector: {np.linalg.norm(p)}")
-    print(f"Linf norm of pressure coefficient vector: {np.abs(u).max()}")
-    print(f"Linf norm of pressure coefficient vector: {np.abs(p).max()}")
-    write_xdmf("StokesDuctPressure", msh, "f", p)
-    write_xdmf("StokesDuctVelcoity", msh, "f", u)                 # (sic) file name of the reference :255
+    if _rank() == 0:
+        print(f"L1 norm of velocity coefficient vector: {np.linalg.norm(u.ravel())}")
+        print(f"L1 norm of pressure coefficient vector: {np.linalg.norm(p)}")
+        print(f"Linf norm of pressure coefficient vector: {np.abs(u).max()}")
+        print(f"Linf norm of pressure coefficient vector: {np.abs(p).max()}")
+        write_xdmf("StokesDuctPressure", msh, "f", p)
+        write_xdmf("StokesDuctVelcoity", msh, "f", u)             # (sic) file name of the reference :255
     P.close()
     return msh, W, res
 
@@ -280,10 +312,12 @@ def lid_driven_main(argv=None):
     P = _problem(msh, B.cavity_bcs(msh), reynolds=float(Re))
     U, res = P.stokes_solve()
     print("Solved Stokes Flow")
-    w, u, p = solve_navier_stokes(P, U.clone())
-    print(f"run time = {time.time() - t0: 0.2f} sec")
-    write_xdmf(f"NavierStokesLidDrivenPressureLinear{Re}", msh, "Pressure", p.cpu().numpy())
-    write_xdmf(f"NavierStokesLidDrivenPressureVelocity{Re}", msh, "Velocity", u.cpu().numpy())
+    w, u, p = solve_navier_stokes(P, U.clone(), _rank())
+    wg = _to_global_host(P, w)
+    if _rank() == 0:
+        print(f"run time = {time.time() - t0: 0.2f} sec")
+        write_xdmf(f"NavierStokesLidDrivenPressureLinear{Re}", msh, "Pressure", wg.reshape(-1, 4)[:, 3].copy())
+        write_xdmf(f"NavierStokesLidDrivenPressureVelocity{Re}", msh, "Velocity", wg.reshape(-1, 4)[:, :3].copy())
     r = P.last_newton
     P.close()
-    return msh, w.cpu().numpy(), r
+    return msh, wg, r

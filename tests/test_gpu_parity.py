@@ -390,3 +390,26 @@ def test_n_rank_solver_through_team_transport(gpu, nranks):
         assert (r.its, n.ksp_its) == (outs[0][2].its, outs[0][4].ksp_its)      # every rank took the same decisions
     assert rel(Ug, Us) < 1e-6 and rel(wg, ws) < 1e-8
     assert outs[0][2].its <= 2 * rs.its + 4                                   # coarse correction stays global
+
+
+@pytest.mark.parametrize("kind,Re,n", [("cavity", 100.0, 12), ("channel", 30.0, 8)])
+def test_newton_fields_vs_oracle_lu_newton(gpu, kind, Re, n):
+    """BASELINE configs 3/4 at reduced size: converged velocity vs the oracle's LU-Newton, < 1e-6 (north_star)."""
+    from oracle import solve as S
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    if kind == "cavity":
+        m = M.cavity_mesh(n)
+        mask, g = B.cavity_bcs(m).flatten()
+    else:
+        m = M.channel_mesh((4 * n, n, n))
+        mask, g = B.channel_bcs(m, *B.two_stream_profiles(0.5)).flatten()
+    Uo, _ = S.solve_stokes(m.points, m.tets, mask, g)
+    wo, info = S.newton(m.points, m.tets, Uo, Re, mask, g)
+    P = gpu(m, (mask, g), reynolds=Re)
+    U, r = P.stokes_solve()
+    w, res = P.newton_solve(U.clone())
+    assert info["reason"] > 0 and res.reason > 0 and abs(res.its - info["its"]) <= 1
+    wg = w.cpu().numpy().reshape(-1, 4)
+    assert rel(wg[:, :3], wo.reshape(-1, 4)[:, :3]) < 1e-6
+    assert rel(wg[:, 3], wo.reshape(-1, 4)[:, 3]) < 1e-5
+    P.close()
