@@ -12,10 +12,12 @@
 What is kept: argv, the Stokes -> coarse NS -> fine NS continuation (:513-530),
 boundary-condition sets, solver settings, printed diagnostics, output folder /
 file names.  What differs, because gmsh / skimage / dolfinx do not exist offline
-(SURVEY 8f, next-row 2): ``<img_fname>`` may be a gmsh ``.msh`` file (tags
-inlet_1=1, inlet_2=2, outlet=3, wall=4), otherwise the 4x1x1 channel is meshed by
-the built-in box mesher with a centred square inner stream and analytic inlet
-profiles normalised exactly like image2inlet.py:323-339.  DuctStokesFlow keeps
+(SURVEY 8f, next-row 2): an existing inlet PNG is processed on its pixel grid
+(inlet_image.py: regions, Poisson profiles, flow-ratio scaling as image2inlet.py:
+240-339, nozzle walls as no-slip nodes) and drives a structured 4x1x1 box channel;
+``<img_fname>`` may also be a gmsh ``.msh`` file (tags inlet_1=1, inlet_2=2,
+outlet=3, wall=4); with neither, a centred square inner stream with analytic
+profiles of the same normalisation is used.  DuctStokesFlow keeps
 the geometry/BCs/CLI of the reference file but solves the P1-P1 stabilised form
 (the north-star discretisation), not its P2-P1 + MUMPS one.
 """
@@ -85,6 +87,23 @@ def generate_mesh(img_fname: str, channel_mesh_size: float):
 def create_boundary_conditions(msh, flowrate_ratio):
     p1, p2 = B.two_stream_profiles(flowrate_ratio, msh.meta.get("inner_half_width", 0.25))
     return B.channel_bcs(msh, p1, p2)
+
+
+def channel_problem_inputs(img_fname: str, flowrate_ratio: float, channel_mesh_size: float):
+    """(mesh, bcs) of one continuation stage (generate_mesh + create_boundary_conditions, :107-147).
+    An existing image drives the inlet as in image2inlet.py (pixel-grid restatement, inlet_image.py);
+    a ``.msh`` file is read as is; anything else falls back to the synthetic centred-square inlet."""
+    is_img = img_fname.lower().endswith((".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff")) and os.path.exists(img_fname)
+    if is_img:
+        from .inlet_image import channel_from_image
+        if _rank() == 0:
+            print("Meshing", flush=True)
+        msh, bcs, _ = channel_from_image(img_fname, flowrate_ratio, lc_to_cells(channel_mesh_size))
+        if _rank() == 0:
+            print(f"Num elem: {msh.num_tets}", flush=True)
+        return msh, bcs
+    msh = generate_mesh(img_fname, channel_mesh_size)
+    return msh, create_boundary_conditions(msh, flowrate_ratio)
 
 
 # --------------------------------------------------------------------------- #
@@ -213,8 +232,7 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     if rank == 0:
         print("Accepted Inputs", flush=True)
     # Solve Stokes Flow
-    msh = generate_mesh(img_fname, coarse_mesh_size)
-    bcs = create_boundary_conditions(msh, flowrate_ratio)
+    msh, bcs = channel_problem_inputs(img_fname, flowrate_ratio, coarse_mesh_size)
     P = _problem(msh, bcs, reynolds=float(Re), ksp_type=snes_ksp_type, device=device)
     U_stokes = solve_stokes_problem(P, rank)
     # Solve Coarse Navier Stokes
@@ -224,8 +242,7 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     w_coarse_host = _to_global_host(P, w_coarse)
     P.close()
     # Solve Navier Stokes With User Defined Mesh
-    msh_f = generate_mesh(img_fname, channel_mesh_size)
-    bcs_f = create_boundary_conditions(msh_f, flowrate_ratio)
+    msh_f, bcs_f = channel_problem_inputs(img_fname, flowrate_ratio, channel_mesh_size)
     Pf = _problem(msh_f, bcs_f, reynolds=float(Re), ksp_type=snes_ksp_type, device=device)
     if rank == 0:
         print("Interpolating Coarse NS Flow", flush=True)
@@ -257,8 +274,7 @@ def stokes_channel_main(argv=None):
     img_fname, ratio = argv[1], float(argv[2])
     mesh_size = float(argv[3]) if len(argv) == 4 else 0.25
     t0 = time.perf_counter()
-    msh = generate_mesh(os.path.abspath(img_fname), mesh_size)
-    bcs = create_boundary_conditions(msh, ratio)
+    msh, bcs = channel_problem_inputs(os.path.abspath(img_fname), ratio, mesh_size)
     P = _problem(msh, bcs, ksp_type="bicgstab", ksp_rtol=1e-10, ksp_atol=1e-10)
     print("\nStart Assembling Stiffness Matrix and Forcing Vector", flush=True)
     U, res = P.stokes_solve()

@@ -342,6 +342,15 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     monkeypatch.chdir(tmp_path)
     r = D.navier_stokes_channel_main(["NavierStokesChannelFlow.py", "5", "./InletImages/Synthetic.png", "0.5", "0.2"])
     assert r["newton"].reason > 0
+    # a real inlet image (dark band = nozzle wall) through the same command line
+    from PIL import Image, ImageDraw
+    os.makedirs("InletImages", exist_ok=True)
+    im = Image.new("RGBA", (160, 160), (255, 255, 255, 255))
+    ImageDraw.Draw(im).rectangle([40, 40, 120, 120], outline=(0, 0, 0, 255), width=8)
+    im.save("InletImages/Box.png")
+    r2 = D.navier_stokes_channel_main(["NavierStokesChannelFlow.py", "5", "./InletImages/Box.png", "0.4", "0.125"])
+    assert r2["newton"].reason > 0 and r2["msh"].meta["kind"] == "channel-image"
+    assert (tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC0125_Box" / "Re5ChannelVelocity.xdmf").exists()
     folder = tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC02_Synthetic"
     assert (folder / "Re5ChannelVelocity.xdmf").exists() and (folder / "RunParameters.txt").exists()
     u = np.fromfile(folder / "Re5ChannelVelocity_Velocity.bin").reshape(-1, 3)

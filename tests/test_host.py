@@ -178,3 +178,33 @@ def test_cli_contracts_and_interpolation(tmp_path, monkeypatch):
     assert np.fromfile(tmp_path / "v_Velocity.bin").size == 3 * c.num_nodes
     D.write_run_metadata(folder, 10, img, 0.5, 0.04, c)
     assert open(os.path.join(folder, "RunParameters.txt")).readline() == "Re=10\n"
+
+
+def test_image_inlet_pipeline(tmp_path):
+    """Pixel-grid restatement of image2inlet.solve_inlet_profiles (:294-353): two regions separated by a dark
+    band, Poisson profiles with unit mean scaled to ratio/area and (1-ratio)/area."""
+    from PIL import Image, ImageDraw
+    from stabilized_navier_stokes_flow_fenicsx_amd import inlet_image as II
+    im = Image.new("RGBA", (200, 200), (255, 255, 255, 255))
+    ImageDraw.Draw(im).ellipse([50, 60, 150, 140], outline=(0, 0, 0, 255), width=8)
+    f = str(tmp_path / "ring.png")
+    im.save(f)
+    D = II.solve_inlet_profiles(f, 0.3)
+    px = 1.0 / D.gray.size
+    assert abs(D.u1.sum() * px - 0.3) < 1e-12 and abs(D.u2.sum() * px - 0.7) < 1e-12     # flow rates = ratio split
+    assert D.area_1 < D.area_2 and abs(D.area_1 + D.area_2 + (D.region == 0).mean() - 1.0) < 1e-12
+    assert D.region_at(0.0, 0.0) == 1 and D.region_at(-0.45, 0.45) == 2                   # centre inner, corner outer
+    assert np.all(D.u1[D.region != 1] == 0) and np.all(D.u2[D.region != 2] == 0) and D.u1.max() > D.u2.max()
+    m, (mask, g), _ = II.channel_from_image(f, 0.3, (12, 10, 10))
+    t = m.meta["tags"]
+    assert len(m.find(t["inlet_1"])) > 0 and len(m.find(t["inlet_2"])) > len(m.find(t["inlet_1"]))
+    inl1 = m.facet_nodes(t["inlet_1"])
+    assert g[4 * inl1].max() > 0 and np.all(g[4 * inl1 + 1] == 0)                         # x-component only (:150-157)
+    # nozzle wall: band nodes with x <= 0.5 are no-slip, none beyond
+    band = (D.region_at(m.points[:, 1], m.points[:, 2]) == 0)
+    interior = (np.abs(m.points[:, 1]) < 0.49) & (np.abs(m.points[:, 2]) < 0.49)
+    near, far = band & interior & (m.points[:, 0] < 0.4), band & interior & (m.points[:, 0] > 0.6) & (m.points[:, 0] < 3.9)
+    assert near.any() and np.all(mask[4 * np.nonzero(near)[0]] == 1) and np.all(mask[4 * np.nonzero(far)[0]] == 0)
+    with pytest.raises(ValueError):
+        Image.new("L", (64, 64), 255).save(str(tmp_path / "blank.png"))
+        II.solve_inlet_profiles(str(tmp_path / "blank.png"), 0.5)
