@@ -196,10 +196,49 @@ def cavity_mesh(n: int = 16, *, jitter: float = 0.0) -> TetMesh:
 
 
 # --------------------------------------------------------------------------- #
+# locality ordering for meshes that arrive in arbitrary order (gmsh)
+# --------------------------------------------------------------------------- #
+def _morton_key(points: np.ndarray, bits: int = 20) -> np.ndarray:
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    q = ((points - lo) / np.maximum(hi - lo, 1e-300) * ((1 << bits) - 1)).astype(np.uint64)
+
+    def spread(v):
+        v = v & np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+
+
+def reorder_for_locality(mesh: TetMesh):
+    """Renumber nodes along a Morton (Z-order) curve and sort tets by their lowest node.
+
+    gmsh writes nodes and cells in meshing order; the SpMV's x-gather and the assembly's
+    gather lists want neighbours to be close in memory (data layout).  The
+    CELL-LOCAL vertex order of every tet is untouched (the G metric depends on it).
+    Returns (new_mesh, perm) with ``new_points = old_points[perm]``.
+    """
+    perm = np.argsort(_morton_key(mesh.points), kind="stable")
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    tets = inv[mesh.tets].astype(np.int32)
+    order = np.argsort(tets.min(axis=1), kind="stable")
+    facets = inv[mesh.facets].astype(np.int32) if len(mesh.facets) else mesh.facets
+    new = TetMesh(np.ascontiguousarray(mesh.points[perm]), np.ascontiguousarray(tets[order]), facets,
+                  mesh.facet_tags.copy(), name=mesh.name, meta=dict(mesh.meta))
+    return new, perm
+
+
+# --------------------------------------------------------------------------- #
 # gmsh .msh reader (ASCII 2.2 and 4.1), tets (type 4) + triangles (type 2)
 # --------------------------------------------------------------------------- #
-def read_msh(path: str) -> TetMesh:
-    """Read tets and tagged boundary triangles from a gmsh ASCII file.
+def read_msh(path: str, reorder: bool = True) -> TetMesh:
+    """Read tets and tagged boundary triangles from a gmsh ASCII file
+    (nodes renumbered for locality unless ``reorder=False``).
 
     Mirrors what ``gmshio.model_to_mesh`` / ``read_from_msh`` deliver to the
     reference (NavierStokesChannelFlow.py:111, DFG_3D_Validation.py:79): only
@@ -239,8 +278,9 @@ def read_msh(path: str) -> TetMesh:
         pts, tets = pts[used], new[tets].astype(np.int32)
         keep = np.all(new[tris] >= 0, axis=1) if len(tris) else np.zeros(0, bool)
         tris, tri_tags = new[tris[keep]].astype(np.int32), np.asarray(tri_tags)[keep]
-    return TetMesh(np.ascontiguousarray(pts), np.ascontiguousarray(tets), np.ascontiguousarray(tris),
-                   np.asarray(tri_tags, dtype=np.int32), name=path, meta={"kind": "msh", "version": ver})
+    out = TetMesh(np.ascontiguousarray(pts), np.ascontiguousarray(tets), np.ascontiguousarray(tris),
+                  np.asarray(tri_tags, dtype=np.int32), name=path, meta={"kind": "msh", "version": ver})
+    return reorder_for_locality(out)[0] if reorder else out
 
 
 def _read_msh2(sec):

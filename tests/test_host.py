@@ -36,7 +36,7 @@ def test_msh_roundtrip_preserves_cell_local_order(tmp_path):
     m = M.channel_mesh((3, 2, 2))
     p = str(tmp_path / "c.msh")
     M.write_msh2(m, p)
-    r = M.read_msh(p)
+    r = M.read_msh(p, reorder=False)
     assert np.array_equal(r.tets, m.tets) and np.allclose(r.points, m.points)
     assert sorted(map(tuple, np.sort(r.facets, 1))) == sorted(map(tuple, np.sort(m.facets, 1)))
     assert set(r.facet_tags) == {1, 2, 3, 4}
@@ -73,7 +73,7 @@ $EndElements
 """
     p = tmp_path / "t.msh"
     p.write_text(txt)
-    r = M.read_msh(str(p))
+    r = M.read_msh(str(p), reorder=False)
     assert r.num_tets == 1 and list(r.tets[0]) == [1, 0, 2, 3]          # file order kept
     assert list(r.facet_tags) == [7] and list(r.facets[0]) == [0, 1, 2]
 
@@ -208,3 +208,18 @@ def test_image_inlet_pipeline(tmp_path):
     with pytest.raises(ValueError):
         Image.new("L", (64, 64), 255).save(str(tmp_path / "blank.png"))
         II.solve_inlet_profiles(str(tmp_path / "blank.png"), 0.5)
+
+
+def test_locality_reordering_keeps_geometry_and_local_order():
+    rng = np.random.default_rng(3)
+    m = M.duct_mesh((6, 4, 4), 3.0, jitter=0.2)
+    shuf = rng.permutation(m.num_nodes)                       # scramble like a gmsh file
+    inv = np.empty_like(shuf); inv[shuf] = np.arange(len(shuf))
+    scr = M.TetMesh(m.points[shuf], inv[m.tets][rng.permutation(m.num_tets)].astype(np.int32),
+                    inv[m.facets].astype(np.int32), m.facet_tags.copy())
+    r, perm = M.reorder_for_locality(scr)
+    assert np.allclose(r.points, scr.points[perm])
+    key = lambda mm: sorted(map(tuple, np.round(mm.points[mm.tets].reshape(len(mm.tets), -1), 12)))
+    assert key(r) == key(scr)                                 # same tets, same cell-local vertex order
+    band = lambda mm: np.abs(mm.tets.max(axis=1) - mm.tets.min(axis=1)).mean()
+    assert band(r) < 0.6 * band(scr)                           # neighbours end up closer in memory
