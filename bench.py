@@ -104,15 +104,19 @@ def main():
     if world != max(1, args.gpus) and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = bool(os.environ.get("SNS_FORCE_DIST"))          # rehearse the partitioned path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     cells = tuple(int(c) for c in args.cells.split(","))
     mesh = M.duct_mesh(cells, 4.0)
     bcs = B.duct_bcs(mesh)
     opts = dict(reynolds=args.re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
-    if world > 1:
+    if world > 1 or force_dist:
         P = FlowProblem.distributed(mesh, bcs, device=f"cuda:{local_rank}", **opts)
     else:
         P = FlowProblem(mesh, bcs, device=f"cuda:{local_rank}", **opts)
@@ -208,7 +212,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     P.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
