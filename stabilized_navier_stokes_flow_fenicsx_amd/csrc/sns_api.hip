@@ -205,11 +205,11 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
     const bool fine = (&L == &h->levels[0]);
     if (fine) {
         time_begin(h, MODE);
-        hipLaunchKernelGGL((k_spmv<MODE, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
+        hipLaunchKernelGGL((k_spmv<MODE, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
                            x, y, b, L.dinv, omega, dotw, h->partial);
         time_end(h);
     } else if constexpr (MODE != SPMV_AX_DOT) {
-        hipLaunchKernelGGL((k_spmv<MODE, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
+        hipLaunchKernelGGL((k_spmv<MODE, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
                            x, y, b, L.dinv, omega, dotw, h->partial);
     }
 }
@@ -226,11 +226,11 @@ void launch_pc_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, d
     if (grid == 0) return;
     if (&L == &h->levels[0]) {
         time_begin(h, MODE);
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
                            L.vals32, x, y, b, L.dinv, omega);
         time_end(h);
     } else {
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
                            L.vals32, x, y, b, L.dinv, omega);
     }
 }
@@ -1485,6 +1485,44 @@ int sns_bench_spmv(sns_handle h, const double* x, double* y, int reps, double* m
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_avg = ms / reps;
+    HIP_TRY(hipGetLastError());
+    return SNS_OK;
+}
+// interleaved A/B micro-benchmark of kernel variants on the assembled level-0 operator (methodology:
+// variants timed alternately in ONE process).  which 0: fp64 y=Ax, 1: fp32-matrix Jacobi sweep;
+// variant 0/1 = default / non-temporal matrix loads.  ms_out[2] = average ms of variant 0 and 1.
+int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]) {
+    if (!h || !ms_out || rounds <= 0 || reps <= 0) return SNS_E_ARG;
+    if (!h->has_matrix) { set_error("bench_variants before a matrix was assembled"); return SNS_E_STATE; }
+    Level& L = h->levels[0];
+    const int32_t rows = h->n_owned;
+    double *x, *y, *b;
+    SNS_TRY(get_vec(h, 10, &x)); SNS_TRY(get_vec(h, 11, &y)); SNS_TRY(get_vec(h, 12, &b));
+    hipLaunchKernelGGL(k_fill_pattern, dim3(vec_grid(4 * (int64_t)rows)), dim3(256), 0, h->stream, 4 * (int64_t)rows, x);
+    if (which >= 1 && !L.vals32) { set_error("fp32 matrix copy not built (pc_setup with amg_f32_matrix)"); return SNS_E_STATE; }
+    double tot[2] = {0, 0};
+    for (int r = 0; r < rounds; ++r)
+        for (int v = 0; v < 2; ++v) {
+            HIP_TRY(hipEventRecord(h->ev0, h->stream));
+            for (int i = 0; i < reps; ++i) {
+                if (which == 0) {
+                    const int grid = (rows + 31) / 32;
+                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
+                    else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
+                } else {
+                    const int grid = (rows + 63) / 64;
+                    if (v) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                    else hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                }
+            }
+            HIP_TRY(hipEventRecord(h->ev1, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            tot[v] += ms / reps;
+        }
+    ms_out[0] = tot[0] / rounds;
+    ms_out[1] = tot[1] / rounds;
     HIP_TRY(hipGetLastError());
     return SNS_OK;
 }

@@ -21,11 +21,11 @@ __global__ void k_gather_matrix(int64_t nnzb, const int64_t* c_ptr, const int32_
 __global__ void k_gather_residual(int32_t n_rows, const int64_t* nt_ptr, const int32_t* nt_idx,
                                   const uint8_t* bc_mask, const double* bc_val, const double* w, const double* Fe,
                                   double* F);
-template <int MODE, int FINE>
+template <int MODE, int FINE, int NT>
 __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial);
-template <int MODE, int FINE>
+template <int MODE, int FINE, int NT>
 __global__ void k_spmv_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const float* vals,
                            const double* x, double* y, const double* bvec, const double* dinv, double omega);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
