@@ -86,12 +86,14 @@ typedef struct {
     int    amg_max_levels;  /* 12                                                    */
     int    amg_coarse_size; /* stop coarsening at <= this many nodes (dense solve)   */
     int    amg_agg_size;    /* max nodes per aggregate (8)                           */
-    int    amg_nu;          /* pre = post smoothing sweeps (2)                       */
+    int    amg_nu;          /* pre = post smoothing sweeps on the fine level (1)     */
     double amg_omega;       /* block-Jacobi damping (0.8)                            */
     int    monitor;         /* 1: print ||r|| per Krylov/Newton iteration (ksp_monitor / snes_monitor :201,:276) */
     int    corrected_convection; /* 0 = reference as written (dot(u,grad(.)) :241,:247); 1 = (u.grad)(.) */
     int    amg_f32_matrix;  /* 1: the AMG smoother/residual passes read an fp32 copy of each level
                                operator (vectors and arithmetic stay fp64; the Krylov operator stays fp64) */
+    int    amg_nu_coarse;   /* smoothing sweeps on levels >= 1 (4; 0 = same as amg_nu): coarse sweeps are
+                               cheap and plain aggregation needs them (V(1,1)+4: 45 its/201 ms vs V(2,2): 54/323) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

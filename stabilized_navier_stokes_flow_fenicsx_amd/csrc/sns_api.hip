@@ -591,7 +591,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         }
         return SNS_OK;
     }
-    const int nu = std::max(1, h->opt.amg_nu);
+    const int nu = std::max(1, (l > 0 && h->opt.amg_nu_coarse > 0) ? h->opt.amg_nu_coarse : h->opt.amg_nu);
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
@@ -1026,11 +1026,12 @@ void sns_default_options(sns_options* o) {
     o->amg_max_levels = 12;
     o->amg_coarse_size = 32;
     o->amg_agg_size = 8;
-    o->amg_nu = 2;
+    o->amg_nu = 1;
     o->amg_omega = 0.8;
     o->monitor = 0;
     o->corrected_convection = 0;
     o->amg_f32_matrix = 1;
+    o->amg_nu_coarse = 4;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
