@@ -461,9 +461,12 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
 }
 
 // ---- preconditioner -----------------------------------------------------------
+int get_vec(sns_ctx* h, size_t k, double** out);
 // |lambda|max of Dinv*A on level l by a few power iterations (device resident; one host sync).
 // The damped block-Jacobi smoother x += w Dinv (b - A x) needs w*|lambda|max < 2; on the reference's
-// operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at 1.5/|lambda|max (smoothing-optimal damping is ~4/(3 lambda_max)).
+// operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at the smoothing-optimal 4/(3 |lambda|max).  (Measured cliff on the coarse
+// levels of the 10 M-tet Jacobian: w = 0.80 converges in 45 iterations, w >= 0.82 overflows, although the
+// dominant mode itself is still damped there -- the offending mode is not the one of largest modulus.)
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     Level& L = h->levels[l];
     const int32_t rows = L.n_owned;
@@ -476,7 +479,7 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     // overkill; use b of the last solve if any, else the diagonal-inverse row sums: simplest robust choice = all ones
     hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, x);
     double lam = 0.0;
-    const int iters = 8;
+    const int iters = 12;
     for (int it = 0; it < iters; ++it) {
         launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
         hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
@@ -490,7 +493,41 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     // x was normalised each step, so ||z|| of the last steps estimates |lambda|max; take the max of the tail
     for (int it = iters - 3; it < iters; ++it) lam = std::max(lam, std::sqrt(v[2 * it + 1]));
     *out = lam;
-    // scratch vectors must be left zero in their ghost tails / unused parts: they were only written on [0, nd)
+    return SNS_OK;
+}
+
+// Growth factor per sweep of the damped block-Jacobi iteration matrix G_w = I - w Dinv A on the
+// dominant mode of Dinv A (left in pong[l] by estimate_lambda_max).  |lambda|max alone does not bound
+// the stable damping of a NON-symmetric operator (|1 - w lambda| < 1 needs w < 2 Re(lambda)/|lambda|^2):
+// on the 10 M-tet Jacobian w = 0.8 converges and w = 0.85 on the coarse levels breaks BiCGStab down.
+int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
+    Level& L = h->levels[l];
+    const int32_t rows = L.n_owned;
+    const int64_t nd = 4 * (int64_t)rows;
+    const int g = vec_grid(nd);
+    double* x0 = h->pong[l];
+    double* xa = L.x;
+    double* xb = L.r;
+    double* zero = nullptr;
+    SNS_TRY(get_vec(h, 13, &zero));                      // level sizes never exceed the fine level
+    HIP_TRY(hipMemsetAsync(zero, 0, nd * sizeof(double), h->stream));
+    // keep x0 intact (it seeds later trials): first sweep x0 -> xa, then ping-pong xa <-> xb
+    launch_spmv<SPMV_JACOBI>(h, L, rows, x0, xa, zero, omega, nullptr);
+    double* cur = xa;
+    double* oth = xb;
+    const int sweeps = 6;
+    for (int s = 1; s < sweeps; ++s) {
+        if (s == 2 || s == sweeps - 1) {
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, cur, cur, h->partial);
+            reduce_local(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2));
+        }
+        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, zero, omega, nullptr);
+        std::swap(cur, oth);
+    }
+    double v[4];
+    SNS_TRY(fetch(h, h->d_scal + 48, 4, v));             // ||x_2||^2, ||x_{sweeps-1}||^2
+    *growth = (v[0] > 0.0) ? std::pow(v[2] / v[0], 0.5 / (double)(sweeps - 1 - 2)) : 0.0;
+    // scratch vectors: only [0, nd) was written; ghost tails stay untouched
     return SNS_OK;
 }
 
@@ -512,8 +549,22 @@ int pc_setup(sns_ctx* h) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
             double lam = L.lambda_max;
             if (!(lam > 0.0) || (h->pc_setups & 3) == 0) SNS_TRY(estimate_lambda_max(h, l, &lam));
+            const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0;
             L.lambda_max = lam;
-            if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, 1.5 / lam);
+            if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam);
+            if (fresh && lam > 0.0) {
+                // verify the damping on the dominant mode; back off until a sweep contracts it by >= 10 %
+                for (int trial = 0; trial < 6; ++trial) {
+                    double gr = 0.0;
+                    SNS_TRY(jacobi_growth(h, l, L.omega, &gr));
+                    if (h->opt.monitor) std::printf("    AMG level %d: omega %.4f growth/sweep on dominant mode %.4f\n", l, L.omega, gr);
+                    if (gr < 0.9) break;
+                    L.omega *= 0.9;
+                }
+                L.omega_checked = L.omega;
+            } else if (L.omega_checked > 0.0) {
+                L.omega = std::min(L.omega, L.omega_checked);
+            }
             if (h->opt.monitor) std::printf("    AMG level %d: n %d |lambda|max(Dinv A) %.4f omega %.4f\n", l, rows, lam, L.omega);
         }
         if (l + 1 < nl) {
@@ -1170,9 +1221,12 @@ int sns_set_stream(sns_handle h, void* s) {
 }
 int sns_set_options(sns_handle h, const sns_options* o) {
     if (!h || !o) return SNS_E_ARG;
-    const bool pc_changed = (o->pc_type != h->opt.pc_type);
+    const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix);
+    const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
     h->opt = *o;
-    if (pc_changed) h->pc_ready = false;
+    if (pc_changed || damping_changed) h->pc_ready = false;
+    if (damping_changed)
+        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }   // re-estimate and re-verify
     return SNS_OK;
 }
 int sns_get_options(sns_handle h, sns_options* o) {

@@ -64,9 +64,10 @@ struct Level {
     double* xg = nullptr;                // distributed runs: copy of the iterate whose ghost tail is exchanged
     // coarsest level: dense inverse (4n x 4n), row-major
     double* dense_inv = nullptr;
-    // block-Jacobi damping actually used on this level (<= amg_omega, limited by 1.5/|lambda|max(Dinv A))
+    // block-Jacobi damping actually used on this level (<= amg_omega, limited by 4/(3 |lambda|max(Dinv A)))
     double omega = 0.8;
     double lambda_max = 0.0;
+    double omega_checked = 0.0;          // damping that passed the growth test at the last fresh estimate
 };
 
 void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc);
