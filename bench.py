@@ -62,7 +62,7 @@ def cpu_baseline(sample_cells=(140, 35, 35), re_full=200.0, full_ny=75):
                       f"||F|| {np.linalg.norm(F):.2e} -> {np.linalg.norm(Fn):.2e}"}
 
 
-def pmc_traffic(kernel_substr="k_spmv<2, 1>"):
+def pmc_traffic(kernel_substr="k_spmv<2, 1"):
     """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc CSVs
     (profiles/*pmc*counter_collection.csv), corrected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE is in KiB and reads half the bytes of a wide streaming read on gfx950 (x2);
@@ -181,7 +181,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("k_spmv_f32<2, 1>" if f32 else "k_spmv<2, 1>"),
+                    "traffic": pmc_traffic("k_spmv_f32<2, 1" if f32 else "k_spmv<2, 1"),
                     "kernel": kname, "avg_launch_ms": round(avg_ms, 5),
                     "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
                     "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}

@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -87,6 +88,11 @@ struct sns_ctx {
     int* d_sing = nullptr;
     bool has_matrix = false, pc_ready = false;
     int pc_setups = 0;
+    // hipGraph of the launch-bound coarse part of the V-cycle (levels >= graph_level; serial runs only)
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t coarse_graph = nullptr;
+    std::vector<double> graph_sig;                // (omega per level, nu, nu_coarse, f32) the graph was captured with
+    bool graph_disabled = false;
     int matrix_form = -1;
     // reductions
     double* partial = nullptr;                   // [2048*8]
@@ -607,6 +613,50 @@ int pc_setup(sns_ctx* h) {
     return SNS_OK;
 }
 
+int vcycle(sns_ctx* h, int l, const double* b, double* x);
+constexpr int GRAPH_LEVEL = 2;     // levels >= 2 of a 10 M-tet hierarchy are ~70 launches of <= 15 us each
+
+// Coarse part of the cycle (level GRAPH_LEVEL and below) as ONE hipGraph launch.  Captured on a private
+// stream (the caller's stream may be the legacy default stream, which cannot be captured), re-captured when
+// the per-level damping or the cycle shape changed.  Distributed runs keep direct launches (the exchange
+// inside the cycle is a host-driven RCCL group).  Any capture failure disables the graph for good.
+int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
+    const bool dist = h->comm && h->comm->active() && h->comm->nranks > 1;
+    if (l != GRAPH_LEVEL || dist || h->graph_disabled || (int)h->levels.size() <= GRAPH_LEVEL + 1)
+        return vcycle(h, l, b, x);
+    std::vector<double> sig;
+    for (auto& L : h->levels) sig.push_back(L.omega);
+    sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_f32_matrix);
+    if (!h->coarse_graph || sig != h->graph_sig) {
+        if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
+        if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+            h->graph_disabled = true;
+            return vcycle(h, l, b, x);
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));          // capture must not race with pending work on the buffers
+        hipStream_t user = h->stream;
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            h->stream = h->cap_stream;
+            const int rc = vcycle(h, l, b, x);
+            h->stream = user;
+            ok = (hipStreamEndCapture(h->cap_stream, &graph) == hipSuccess) && rc == SNS_OK && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&h->coarse_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {
+            (void)hipGetLastError();
+            h->coarse_graph = nullptr;
+            h->graph_disabled = true;
+            return vcycle(h, l, b, x);
+        }
+        h->graph_sig = sig;
+    }
+    HIP_TRY(hipGraphLaunch(h->coarse_graph, h->stream));
+    return SNS_OK;
+}
+
 // V-cycle on level l: x <- approx A_l^-1 b  (x overwritten; zero initial guess)
 int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     Level& L = h->levels[l];
@@ -662,7 +712,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     if (C.n_owned > 0)
         hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
                            C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
-    SNS_TRY(vcycle(h, l + 1, C.b, C.x));
+    SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     for (int s = 0; s < nu; ++s) {
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
@@ -1164,6 +1214,7 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
     // the hierarchy is built lazily (first pc_setup) so that sns_attach_comm can shrink n_owned first
     HIP_TRY(hipDeviceSynchronize());
     h->tm = sns_timings{};
+    h->graph_disabled = std::getenv("SNS_NO_GRAPH") != nullptr;
     h->pattern.reset(new HostPattern(std::move(P)));
     *out = h.release();
     return SNS_OK;
@@ -1201,6 +1252,8 @@ int sns_destroy(sns_handle h) {
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
     fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
+    if (h->coarse_graph) (void)hipGraphExecDestroy(h->coarse_graph);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
