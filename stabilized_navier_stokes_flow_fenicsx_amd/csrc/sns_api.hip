@@ -437,7 +437,26 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
     const int grid = (int)((h->E + EL_TETS_PER_BLOCK - 1) / EL_TETS_PER_BLOCK);
     const double nu = 1.0 / h->opt.reynolds;
     double* Fe = F ? h->Fe : nullptr;
-    if (grid > 0) {
+    bool fast_residual = false;
+    if (!want_matrix && F && form == SNS_FORM_NS && h->E > 0) {
+        // residual only: if the state satisfies the Dirichlet data there is no lifting term (:65) and the
+        // one-lane-per-tet kernel applies; otherwise the general fused kernel computes the lifted blocks
+        const int64_t ndof = 4 * (int64_t)h->n;
+        const int gv = vec_grid(ndof);
+        hipLaunchKernelGGL(k_count_bc_violations, dim3(gv), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w,
+                           h->partial);
+        reduce_local(h, gv, 1, h->d_scal + 60);
+        double nviol = 1.0;
+        SNS_TRY(fetch(h, h->d_scal + 60, 1, &nviol));
+        fast_residual = (nviol == 0.0);
+    }
+    if (fast_residual) {
+        const unsigned gt = (unsigned)((h->E + 255) / 256);
+        if (!h->opt.corrected_convection)
+            hipLaunchKernelGGL((k_residual_tet<false>), dim3(gt), dim3(256), 0, h->stream, h->E, h->tets, h->pts, w, nu, h->Fe);
+        else
+            hipLaunchKernelGGL((k_residual_tet<true>), dim3(gt), dim3(256), 0, h->stream, h->E, h->tets, h->pts, w, nu, h->Fe);
+    } else if (grid > 0) {
         if (form == SNS_FORM_STOKES)
             hipLaunchKernelGGL((k_element<SNS_FORM_STOKES, false>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
                                h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);

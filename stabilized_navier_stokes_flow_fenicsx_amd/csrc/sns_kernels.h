@@ -16,6 +16,11 @@ template <int FORM, bool corrected>
 __global__ void k_element(int64_t n_tets, const int32_t* tets, const double* pts, const double* w,
                           const uint8_t* bc_mask, const double* bc_val, double nu, int store_K, double* Ke,
                           double* Fe);
+template <bool corrected>
+__global__ void k_residual_tet(int64_t n_tets, const int32_t* tets, const double* pts, const double* w, double nu,
+                               double* Fe);
+__global__ void k_count_bc_violations(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, const double* w,
+                                      double* partial);
 __global__ void k_gather_matrix(int64_t nnzb, const int64_t* c_ptr, const int32_t* c_idx, const int32_t* slot_row,
                                 const int32_t* colind, const uint8_t* bc_mask, const double* Ke, double* vals);
 __global__ void k_gather_residual(int32_t n_rows, const int64_t* nt_ptr, const int32_t* nt_idx,

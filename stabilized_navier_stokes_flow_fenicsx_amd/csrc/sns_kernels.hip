@@ -380,6 +380,120 @@ SNS_INST_ELEMENT(SNS_FORM_STOKES, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, true)
 
+// Residual-only element pass for states that already satisfy the Dirichlet data (no lifting term):
+// ONE LANE PER TET, every lane busy (the fused kernel keeps 12 of 16 lanes idle in its per-point
+// phase).  Used by the line search (F(x - lambda y), :51-67 without the Jacobian).
+template <bool corrected>
+__global__ __launch_bounds__(256) void k_residual_tet(int64_t n_tets, const int32_t* __restrict__ tets,
+                                                      const double* __restrict__ pts,
+                                                      const double* __restrict__ w, double nu,
+                                                      double* __restrict__ Fe) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tets) return;
+    const int4 tv = *reinterpret_cast<const int4*>(tets + 4 * t);
+    const int32_t nd[4] = {tv.x, tv.y, tv.z, tv.w};
+    double X[4][3], W[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double* pp = pts + 3 * (int64_t)nd[a];
+        X[a][0] = pp[0]; X[a][1] = pp[1]; X[a][2] = pp[2];
+        const double2* wp = reinterpret_cast<const double2*>(w + 4 * (int64_t)nd[a]);
+        const double2 w0 = wp[0], w1 = wp[1];
+        W[a][0] = w0.x; W[a][1] = w0.y; W[a][2] = w1.x; W[a][3] = w1.y;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = X[1][i] - X[0][i];
+        J[i][1] = X[2][i] - X[0][i];
+        J[i][2] = X[3][i] - X[0][i];
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double id = 1.0 / det;
+    double K[3][3];
+    K[0][0] = c00 * id; K[1][0] = c01 * id; K[2][0] = c02 * id;
+    K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+    K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+    K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+    K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    double g[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        g[1][j] = K[0][j]; g[2][j] = K[1][j]; g[3][j] = K[2][j];
+        g[0][j] = -(K[0][j] + K[1][j] + K[2][j]);
+    }
+    double G[3][3], trG = 0.0, GG = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            G[i][j] = K[0][i] * K[0][j] + K[1][i] * K[1][j] + K[2][i] * K[2][j];
+            GG += G[i][j] * G[i][j];
+            if (i == j) trG += G[i][j];
+        }
+    double gu[3][3], gp[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gp[j] = W[0][3] * g[0][j] + W[1][3] * g[1][j] + W[2][3] * g[2][j] + W[3][3] * g[3][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i][j] = W[0][i] * g[0][j] + W[1][i] * g[1][j] + W[2][i] * g[2][j] + W[3][i] * g[3][j];
+    }
+    const double divu = gu[0][0] + gu[1][1] + gu[2][2];
+    const double wd = fabs(det) * (1.0 / 24.0);
+    double R[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[a][c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double u[3] = {0.0, 0.0, 0.0}, p = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double ph = phi_q(q, a);
+            u[0] += ph * W[a][0]; u[1] += ph * W[a][1]; u[2] += ph * W[a][2]; p += ph * W[a][3];
+        }
+        double Gu[3], conv[3], r[3], uGu = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Gu[i] = G[i][0] * u[0] + G[i][1] * u[1] + G[i][2] * u[2];
+            uGu += u[i] * Gu[i];
+            conv[i] = gu[i][0] * u[0] + gu[i][1] * u[1] + gu[i][2] * u[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r[j] = (corrected ? conv[j] : (gu[0][j] * u[0] + gu[1][j] * u[1] + gu[2][j] * u[2])) + gp[j];
+        const double tau = 1.0 / sqrt(uGu + 36.0 * nu * nu * GG);
+        const double nuL = 1.0 / (trG * tau);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double pa = phi_q(q, a);
+            const double sa = r[0] * g[a][0] + r[1] * g[a][1] + r[2] * g[a][2];
+            const double uga = u[0] * g[a][0] + u[1] * g[a][1] + u[2] * g[a][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double visc = gu[i][0] * g[a][0] + gu[i][1] * g[a][1] + gu[i][2] * g[a][2];
+                const double supg = corrected ? tau * uga * r[i] : tau * u[i] * sa;
+                R[a][i] += conv[i] * pa + nu * visc - p * g[a][i] + supg + nuL * divu * g[a][i];
+            }
+            R[a][3] += pa * divu + tau * sa;
+        }
+    }
+    double2* o = reinterpret_cast<double2*>(Fe + 16 * t);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        o[2 * a] = make_double2(wd * R[a][0], wd * R[a][1]);
+        o[2 * a + 1] = make_double2(wd * R[a][2], wd * R[a][3]);
+    }
+}
+template __global__ void k_residual_tet<false>(int64_t, const int32_t*, const double*, const double*, double, double*);
+template __global__ void k_residual_tet<true>(int64_t, const int32_t*, const double*, const double*, double, double*);
+
 // BSR slot <- sum over its contributing element blocks (fixed order => bitwise
 // reproducible), Dirichlet rows AND columns zeroed, unit diagonal (:74).
 // 8 lanes per slot, lane = two adjacent entries (16-B loads): each contribution is one
@@ -740,6 +854,16 @@ __global__ __launch_bounds__(256) void k_reduce_final(int nblocks, int nred, con
         __syncthreads();
     }
     if (threadIdx.x == 0) out[k] = red[0];
+}
+
+// partial[block] = number of Dirichlet dofs whose current value differs from the prescribed one
+__global__ __launch_bounds__(256) void k_count_bc_violations(int64_t ndof, const uint8_t* __restrict__ bc_mask,
+                                                             const double* __restrict__ bc_val,
+                                                             const double* __restrict__ w, double* __restrict__ partial) {
+    double v[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndof; i += (int64_t)gridDim.x * blockDim.x)
+        if (bc_mask[i] && w[i] != bc_val[i]) v[0] += 1.0;
+    block_reduce_store<1>(v, partial);
 }
 
 // generic: out[0] = x.y, out[1] = y.y  (n = number of doubles reduced over)

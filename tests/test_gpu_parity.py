@@ -494,3 +494,27 @@ def test_edge_cases_tiny_and_degenerate_inputs(gpu):
     with pytest.raises(_lib.SnsError):                              # vertex id out of range is rejected on the host
         gpu(M.TetMesh(pts[:4], np.array([[0, 1, 2, 9]], np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32)),
             (np.zeros(16, np.uint8), np.zeros(16)))
+
+
+@pytest.mark.parametrize("corrected", [0, 1])
+def test_fast_residual_path_when_bcs_hold(gpu, corrected):
+    """A state that satisfies the Dirichlet data takes the one-lane-per-tet residual kernel (no lifting);
+    it must agree with the fused kernel's residual and with the oracle."""
+    from oracle import assemble as asm
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.channel_mesh((9, 5, 4), jitter=0.2)
+    mask, g = B.channel_bcs(m, *B.two_stream_profiles(0.4)).flatten()
+    w = np.random.default_rng(21).normal(size=m.num_dofs) * 0.5
+    Bm = mask.astype(bool)
+    w[Bm] = g[Bm]
+    P = gpu(m, (mask, g), reynolds=17.0, corrected_convection=corrected)
+    F_fast = P.residual(_dev(w), "ns").cpu().numpy()            # fast path (no violations)
+    F_fused = P.zeros()
+    P.jacobian(_dev(w), "ns", residual_out=F_fused)            # fused element kernel
+    assert rel(F_fast, F_fused.cpu().numpy()) < 1e-13
+    if not corrected:
+        assert rel(F_fast, asm.residual_ns(m.points, m.tets, w, 17.0, mask, g)) < 1e-12
+    w2 = w.copy(); w2[np.nonzero(Bm)[0][0]] += 0.3               # one violated dof -> general path with lifting
+    if not corrected:
+        assert rel(P.residual(_dev(w2), "ns").cpu().numpy(), asm.residual_ns(m.points, m.tets, w2, 17.0, mask, g)) < 1e-12
+    P.close()
