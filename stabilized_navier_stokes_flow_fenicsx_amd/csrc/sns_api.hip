@@ -1535,6 +1535,7 @@ int sns_newton_solve(sns_handle h, double* w, int* its_out, int* reason_out, int
         else if (f <= o.snes_rtol * f0) reason = SNS_SNES_CONVERGED_FNORM_RELATIVE;
         else if (lam * ynorm < o.snes_stol * xnorm) reason = SNS_SNES_CONVERGED_SNORM_RELATIVE;
         if (reason) break;
+        if (it >= o.snes_max_it) { reason = SNS_SNES_DIVERGED_MAX_IT; break; }   // no Jacobian after the last iteration
         SNS_TRY(timed_assemble(h, SNS_FORM_NS, w, F, true));
     }
     *its_out = it;
