@@ -94,6 +94,7 @@ typedef struct {
                                operator (vectors and arithmetic stay fp64; the Krylov operator stays fp64) */
     int    amg_nu_coarse;   /* smoothing sweeps on levels >= 1 (4; 0 = same as amg_nu): coarse sweeps are
                                cheap and plain aggregation needs them (V(1,1)+4: 45 its/201 ms vs V(2,2): 54/323) */
+    int    amg_nu_deep;     /* sweeps on levels >= 3 (2; 0 = same as amg_nu_coarse): these levels are launch-bound */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

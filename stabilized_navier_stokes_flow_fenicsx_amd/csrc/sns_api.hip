@@ -645,7 +645,8 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
         return vcycle(h, l, b, x);
     std::vector<double> sig;
     for (auto& L : h->levels) sig.push_back(L.omega);
-    sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_f32_matrix);
+    sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_nu_deep);
+    sig.push_back(h->opt.amg_f32_matrix);
     if (!h->coarse_graph || sig != h->graph_sig) {
         if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
         if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -711,7 +712,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         }
         return SNS_OK;
     }
-    const int nu = std::max(1, (l > 0 && h->opt.amg_nu_coarse > 0) ? h->opt.amg_nu_coarse : h->opt.amg_nu);
+    int nu = std::max(1, h->opt.amg_nu);
+    if (l >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;            // launch-bound tiny levels
+    else if (l >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;   // levels 1-2: cheap and effective
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
@@ -1152,6 +1155,7 @@ void sns_default_options(sns_options* o) {
     o->corrected_convection = 0;
     o->amg_f32_matrix = 1;
     o->amg_nu_coarse = 4;
+    o->amg_nu_deep = 2;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
