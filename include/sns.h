@@ -92,9 +92,10 @@ typedef struct {
     int    corrected_convection; /* 0 = reference as written (dot(u,grad(.)) :241,:247); 1 = (u.grad)(.) */
     int    amg_f32_matrix;  /* 1: the AMG smoother/residual passes read an fp32 copy of each level
                                operator (vectors and arithmetic stay fp64; the Krylov operator stays fp64) */
-    int    amg_nu_coarse;   /* smoothing sweeps on levels >= 1 (4; 0 = same as amg_nu): coarse sweeps are
-                               cheap and plain aggregation needs them (V(1,1)+4: 45 its/201 ms vs V(2,2): 54/323) */
+    int    amg_nu_coarse;   /* smoothing sweeps on level 1 (and deeper unless overridden) (4; 0 = same as amg_nu):
+                               coarse sweeps are cheap and plain aggregation needs them */
     int    amg_nu_deep;     /* sweeps on levels >= 3 (2; 0 = same as amg_nu_coarse): these levels are launch-bound */
+    int    amg_nu_l2;       /* sweeps on level 2 (6; 0 = same as amg_nu_coarse) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
