@@ -563,17 +563,19 @@ int pc_setup(sns_ctx* h) {
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
         const int32_t rows = L.n_owned;
-        hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
+        if (rows > 0)
+            hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
         if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             if (!L.vals32) SNS_TRY(dev_alloc(&L.vals32, (size_t)L.nnzb * 16));
-            hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.nnzb * 16)), dim3(256), 0, h->stream, L.nnzb * 16, L.vals,
+            if (L.nnzb > 0)
+                hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.nnzb * 16)), dim3(256), 0, h->stream, L.nnzb * 16, L.vals,
                                L.vals32);
         }
         if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
             double lam = L.lambda_max;
-            if (!(lam > 0.0) || (h->pc_setups & 3) == 0) SNS_TRY(estimate_lambda_max(h, l, &lam));
+            if (rows > 0 && (!(lam > 0.0) || (h->pc_setups & 3) == 0)) SNS_TRY(estimate_lambda_max(h, l, &lam));
             const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0;
             L.lambda_max = lam;
             if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam);
@@ -706,6 +708,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         // coarsest level too large for the dense solve: a fixed number of Jacobi sweeps (still a linear operator)
         double* cur = x;
         double* oth = h->pong[l];
+        if (rows == 0) return SNS_OK;
         hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
         for (int s = 0; s < 8; ++s) {       // even count: result ends in x
             launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
