@@ -210,6 +210,23 @@ int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_de
  * which 0 = fp64 y=Ax, 1 = fp32-matrix Jacobi sweep; ms_out[v] = average launch ms of variant v          */
 int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]);
 
+/* ---- batched particle tracing (next row after the solve path; replaces the per-seed
+ *      solve_ivp(RK45) of NavierStokes/streamtrace.py:208-232, :357-383) ---------------
+ * One lane per seed: scipy's RK45 (same tableau, controller and initial step; rtol/atol as
+ * given, the reference uses solve_ivp's defaults 1e-3 / 1e-6 and max_step 0.125, t in [0,20]).
+ * Velocity = P1 interpolation of vel_dev (n_nodes x 3) in the containing tet, zero outside
+ * (velfunc :144-158); reverse != 0 negates it (:160-173).  Terminal events: speed falling
+ * below speed_min (1e-6, :175-178) -> status 1; x crossing x_stop upward (forward, 3.7 :180-183)
+ * or downward (reverse, 0.13 :185-188) -> status 2; t_end reached -> 0; step underflow -> 3.
+ * nbr_dev[4t+a] = tet across the face opposite local vertex a of tet t, -1 on the boundary;
+ * seed_tet_dev = a tet containing (or near) each seed.  All pointers are device memory.   */
+int sns_streamtrace(int32_t n_nodes, int64_t n_tets, const double* pts_dev, const int32_t* tets_dev,
+                    const int32_t* nbr_dev, const double* vel_dev, int32_t n_seeds,
+                    const double* seeds_dev, const int32_t* seed_tet_dev, int reverse, double t_end,
+                    double max_step, double rtol, double atol, double x_stop, double speed_min,
+                    double* pos_out_dev, double* t_out_dev, int32_t* status_out_dev,
+                    int32_t* steps_out_dev, void* hip_stream);
+
 /* ---- host-only symbolic utilities (no GPU needed; used by sns_create and by
  *      the CPU test-suite) ------------------------------------------------------
  * BSR sparsity pattern of the P1-P1 operator (what create_matrix derives from

@@ -87,6 +87,8 @@ _SIGNATURES = [
     ("sns_bench_spmv", C.c_int, [_H, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     ("sns_bench_assemble", C.c_int, [_H, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     ("sns_bench_variants", C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("sns_streamtrace", C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
 ]
