@@ -362,15 +362,19 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     assert nres.reason > 0 and msh.num_tets == 6 ** 4
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_n_rank_solver_through_team_transport(gpu, nranks):
+@pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity")])
+def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
     exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
     GPU over the in-process team transport; RCCL only replaces the transport on a multi-GPU node."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
     from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
-    m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
-    mask, g = B.duct_bcs(m).flatten()
+    if kind == "duct":
+        m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
+        mask, g = B.duct_bcs(m).flatten()
+    else:                                           # 2 x 2 RCB blocks: up to 3 neighbours per rank, corner ghosts
+        m = M.cavity_mesh(12, jitter=0.1)
+        mask, g = B.cavity_bcs(m).flatten()
     Re = 12.0
     Ps = gpu(m, (mask, g), reynolds=Re)
     Us, rs = Ps.stokes_solve()
