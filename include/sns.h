@@ -96,6 +96,8 @@ typedef struct {
                                coarse sweeps are cheap and plain aggregation needs them */
     int    amg_nu_deep;     /* sweeps on levels >= 3 (2; 0 = same as amg_nu_coarse): these levels are launch-bound */
     int    amg_nu_l2;       /* sweeps on level 2 (6; 0 = same as amg_nu_coarse) */
+    int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
+                               state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

@@ -7,5 +7,7 @@ m = M.duct_mesh(cells, 4.0)
 P = FlowProblem(m, B.duct_bcs(m), reynolds=200.0)
 U, r = P.stokes_solve()
 for rep in range(2):
-    ms = P.bench_assemble(U, "ns", 5)
-    print(f"assemble J+F {ms:.3f} ms -> {2480.0*m.num_tets/ms/1e6:.1f} GB/s algorithmic", flush=True)
+    for fused in (0, 1):
+        P.set_options(assembly_fused=fused)
+        ms = P.bench_assemble(U, "ns", 5)
+        print(f"fused={fused} assemble J+F {ms:.3f} ms -> {2480.0*m.num_tets/ms/1e6:.1f} GB/s algorithmic", flush=True)

@@ -78,6 +78,8 @@ struct sns_ctx {
     // assembly maps
     int64_t *nt_ptr = nullptr, *c_ptr = nullptr;
     int32_t *nt_idx = nullptr, *c_idx = nullptr;
+    int32_t* od_order = nullptr;       // off-diagonal slots, locally sorted by contribution count (scratch-free assembly)
+    int64_t n_od = 0;
     double *Ke = nullptr, *Fe = nullptr;
     // operator hierarchy; levels[0] is the assembled fine operator
     std::vector<Level> levels;
@@ -432,13 +434,11 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
 int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
     if (form != SNS_FORM_STOKES && form != SNS_FORM_NS) { set_error("bad form"); return SNS_E_ARG; }
     if (form == SNS_FORM_NS && !w) { set_error("NS form needs a state vector"); return SNS_E_ARG; }
-    if (want_matrix && !h->Ke) SNS_TRY(dev_alloc(&h->Ke, (size_t)h->E * 256));
-    if (!h->Fe) SNS_TRY(dev_alloc(&h->Fe, (size_t)h->E * 16));
     const int grid = (int)((h->E + EL_TETS_PER_BLOCK - 1) / EL_TETS_PER_BLOCK);
     const double nu = 1.0 / h->opt.reynolds;
-    double* Fe = F ? h->Fe : nullptr;
     bool fast_residual = false;
-    if (!want_matrix && F && form == SNS_FORM_NS && h->E > 0) {
+    const bool try_fused = want_matrix && h->opt.assembly_fused && form == SNS_FORM_NS && h->E > 0;
+    if (((!want_matrix && F) || try_fused) && form == SNS_FORM_NS && h->E > 0) {
         // residual only: if the state satisfies the Dirichlet data there is no lifting term (:65) and the
         // one-lane-per-tet kernel applies; otherwise the general fused kernel computes the lifted blocks
         const int64_t ndof = 4 * (int64_t)h->n;
@@ -450,6 +450,31 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         SNS_TRY(fetch(h, h->d_scal + 60, 1, &nviol));
         fast_residual = (nviol == 0.0);
     }
+    Level& L = h->levels[0];
+    if (fast_residual && want_matrix) {
+        // scratch-free path: every BSR block (and every node residual) is computed by the lanes that own it
+        const unsigned go = (unsigned)((h->n_od + 255) / 256);
+        const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
+        if (!h->opt.corrected_convection) {
+            hipLaunchKernelGGL((k_fused_offdiag<false>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
+                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
+            hipLaunchKernelGGL((k_fused_diag<false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
+        } else {
+            hipLaunchKernelGGL((k_fused_offdiag<true>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
+                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
+            hipLaunchKernelGGL((k_fused_diag<true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
+        }
+        h->has_matrix = true;
+        h->pc_ready = false;
+        h->matrix_form = form;
+        HIP_TRY(hipGetLastError());
+        return SNS_OK;
+    }
+    if (want_matrix && !h->Ke) SNS_TRY(dev_alloc(&h->Ke, (size_t)h->E * 256));
+    if (!h->Fe) SNS_TRY(dev_alloc(&h->Fe, (size_t)h->E * 16));
+    double* Fe = F ? h->Fe : nullptr;
     if (fast_residual) {
         const unsigned gt = (unsigned)((h->E + 255) / 256);
         if (!h->opt.corrected_convection)
@@ -467,7 +492,6 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
             hipLaunchKernelGGL((k_element<SNS_FORM_NS, true>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
                                h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
     }
-    Level& L = h->levels[0];
     if (want_matrix) {
         const int64_t nth = L.nnzb * 8;
         hipLaunchKernelGGL(k_gather_matrix, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.nnzb,
@@ -1165,6 +1189,7 @@ void sns_default_options(sns_options* o) {
     o->amg_nu_coarse = 4;
     o->amg_nu_deep = 2;
     o->amg_nu_l2 = 6;
+    o->assembly_fused = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1218,6 +1243,32 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
     SNS_TRY(dev_upload(&h->nt_idx, M.nt_idx, nullptr));
     SNS_TRY(dev_upload(&h->c_ptr, M.c_ptr, nullptr));
     SNS_TRY(dev_upload(&h->c_idx, M.c_idx, nullptr));
+    {
+        // lane -> slot map of the scratch-free assembly: off-diagonal slots only, and inside every window of
+        // 8192 consecutive slots ordered by descending contribution count, so that the lanes of a wave loop
+        // the same number of times (edge valences differ: 4 or 6 tets on a Kuhn mesh) while their gathers
+        // stay within the same neighbourhood of the mesh
+        const int64_t nnzb = (int64_t)P.colind.size(), WIN = 8192;
+        std::vector<int32_t> order;
+        order.reserve((size_t)nnzb);
+        std::vector<int32_t> row_of((size_t)nnzb);
+        for (int32_t i = 0; i < P.n; ++i)
+            for (int32_t q = P.rowptr[i]; q < P.rowptr[i + 1]; ++q) row_of[(size_t)q] = i;
+        std::vector<std::vector<int32_t>> bucket;
+        for (int64_t s0 = 0; s0 < nnzb; s0 += WIN) {
+            const int64_t s1 = std::min(nnzb, s0 + WIN);
+            for (auto& b : bucket) b.clear();
+            for (int64_t q = s0; q < s1; ++q) {
+                if (P.colind[(size_t)q] == row_of[(size_t)q]) continue;
+                const size_t cnt = (size_t)(M.c_ptr[(size_t)q + 1] - M.c_ptr[(size_t)q]);
+                if (bucket.size() <= cnt) bucket.resize(cnt + 1);
+                bucket[cnt].push_back((int32_t)q);
+            }
+            for (size_t c = bucket.size(); c-- > 0;) order.insert(order.end(), bucket[c].begin(), bucket[c].end());
+        }
+        h->n_od = (int64_t)order.size();
+        SNS_TRY(dev_upload(&h->od_order, order, nullptr));
+    }
     h->levels.reserve(64);
     h->slot_row.reserve(64);
     h->empty_c.reserve(64);
@@ -1272,7 +1323,7 @@ int sns_destroy(sns_handle h) {
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(h->tets); fr(h->pts); fr(h->bc_mask); fr(h->bc_val);
-    fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->Ke); fr(h->Fe);
+    fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32);

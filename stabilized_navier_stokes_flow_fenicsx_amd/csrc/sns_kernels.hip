@@ -380,6 +380,310 @@ SNS_INST_ELEMENT(SNS_FORM_STOKES, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, true)
 
+// quad-permute a double with DPP moves (no LDS, no memory traffic); CTRL = quad_perm encoding
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// ============================================================================
+// K1 (scratch-free variant): every BSR block is produced by the lane(s) that own it.
+// A lane walks the block's contribution list (tet, a, b) and recomputes the element
+// block on the fly, so nothing is staged in HBM: no 2 KiB/tet scratch write, no gather pass,
+// no atomics, fixed summation order (bitwise reproducible).  Costs ~2x the block flops of the
+// staged kernel (geometry + per-point scalars are recomputed per contribution) and only applies
+// when the state satisfies the Dirichlet data (no lifting term, :65), i.e. every Newton iterate
+// after the first update; the staged k_element path handles the rest.
+// ============================================================================
+template <bool corrected>
+__device__ __forceinline__ void tet_block_accumulate(const int4 tv, const double* __restrict__ pts,
+                                                     const double* __restrict__ w, double nu, int a, int b,
+                                                     bool want_res, double acc[16], double Ra[4]) {
+    const int32_t nd[4] = {tv.x, tv.y, tv.z, tv.w};
+    double X[4][3], W[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double* pp = pts + 3 * (int64_t)nd[v];
+        X[v][0] = pp[0]; X[v][1] = pp[1]; X[v][2] = pp[2];
+        const double2* wp = reinterpret_cast<const double2*>(w + 4 * (int64_t)nd[v]);
+        const double2 w0 = wp[0], w1 = wp[1];
+        W[v][0] = w0.x; W[v][1] = w0.y; W[v][2] = w1.x; W[v][3] = w1.y;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = X[1][i] - X[0][i];
+        J[i][1] = X[2][i] - X[0][i];
+        J[i][2] = X[3][i] - X[0][i];
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double id = 1.0 / det;
+    double K[3][3];
+    K[0][0] = c00 * id; K[1][0] = c01 * id; K[2][0] = c02 * id;
+    K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+    K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+    K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+    K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    double g[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        g[1][j] = K[0][j]; g[2][j] = K[1][j]; g[3][j] = K[2][j];
+        g[0][j] = -(K[0][j] + K[1][j] + K[2][j]);
+    }
+    double G[3][3], trG = 0.0, GG = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            G[i][j] = K[0][i] * K[0][j] + K[1][i] * K[1][j] + K[2][i] * K[2][j];
+            GG += G[i][j] * G[i][j];
+            if (i == j) trG += G[i][j];
+        }
+    double gu[3][3], gp[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gp[j] = W[0][3] * g[0][j] + W[1][3] * g[1][j] + W[2][3] * g[2][j] + W[3][3] * g[3][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i][j] = W[0][i] * g[0][j] + W[1][i] * g[1][j] + W[2][i] * g[2][j] + W[3][i] * g[3][j];
+    }
+    const double divu = gu[0][0] + gu[1][1] + gu[2][2];
+    const double wd = fabs(det) * (1.0 / 24.0);
+    const double itrG = 1.0 / trG, nu36GG = 36.0 * nu * nu * GG;
+    // runtime-indexed rows of g: select with predication (keeps everything in registers)
+    double ga[3], gb[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ga[j] = a == 0 ? g[0][j] : (a == 1 ? g[1][j] : (a == 2 ? g[2][j] : g[3][j]));
+        gb[j] = b == 0 ? g[0][j] : (b == 1 ? g[1][j] : (b == 2 ? g[2][j] : g[3][j]));
+    }
+    const double gab = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+    double guga[3], visc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        visc[j] = gu[j][0] * ga[0] + gu[j][1] * ga[1] + gu[j][2] * ga[2];                   // (grad u) g_a
+        guga[j] = corrected ? (ga[0] * gu[0][j] + ga[1] * gu[1][j] + ga[2] * gu[2][j]) : visc[j];
+    }
+    double blk[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) blk[e] = 0.0;
+    double Rq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double u[3] = {0.0, 0.0, 0.0}, p = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double ph = phi_q(q, v);
+            u[0] += ph * W[v][0]; u[1] += ph * W[v][1]; u[2] += ph * W[v][2]; p += ph * W[v][3];
+        }
+        const double pa = phi_q(q, a), pb = phi_q(q, b);
+        double Gu[3], conv[3], r[3], uGu = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Gu[i] = G[i][0] * u[0] + G[i][1] * u[1] + G[i][2] * u[2];
+            uGu += u[i] * Gu[i];
+            conv[i] = gu[i][0] * u[0] + gu[i][1] * u[1] + gu[i][2] * u[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r[j] = (corrected ? conv[j] : (gu[0][j] * u[0] + gu[1][j] * u[1] + gu[2][j] * u[2])) + gp[j];
+        // tau = m^-1/2, nu_LSIC = 1/(trG tau) = m tau / trG: one rsqrt per point, no divisions
+        const double mq = uGu + nu36GG;
+        const double tau = rsqrt(mq);
+        const double nuL = mq * tau * itrG;
+        const double sa = r[0] * ga[0] + r[1] * ga[1] + r[2] * ga[2];
+        const double ugb = u[0] * gb[0] + u[1] * gb[1] + u[2] * gb[2];
+        const double uga = u[0] * ga[0] + u[1] * ga[1] + u[2] * ga[2];
+        const double t3 = tau * tau * tau;
+        double cu[3], cg[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double dtau = -t3 * pb * Gu[j];
+            const double dnuL = (tau * itrG) * pb * Gu[j];
+            cg[j] = dnuL * divu + nuL * gb[j];
+            cu[j] = corrected ? dtau : dtau * sa + tau * (u[j] * gab + pb * guga[j]);
+        }
+        if (!corrected) {
+            const double A1 = pa * ugb + nu * gab + tau * sa * pb;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) blk[4 * i + j] += pa * pb * gu[i][j] + u[i] * cu[j] + ga[i] * cg[j];
+                blk[5 * i] += A1;
+                blk[4 * i + 3] += -pb * ga[i] + tau * u[i] * gab;
+                blk[12 + i] += pa * gb[i] + cu[i];
+            }
+            blk[15] += tau * gab;
+        } else {
+            const double A1 = pa * ugb + nu * gab + tau * uga * ugb;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    blk[4 * i + j] += pa * pb * gu[i][j] + cu[j] * uga * r[i] + tau * pb * ga[j] * r[i] +
+                                      tau * uga * pb * gu[i][j] + ga[i] * cg[j];
+                blk[5 * i] += A1;
+                blk[4 * i + 3] += -pb * ga[i] + tau * uga * gb[i];
+                blk[12 + i] += pa * gb[i] + cu[i] * sa + tau * (ugb * ga[i] + pb * guga[i]);
+            }
+            blk[15] += tau * gab;
+        }
+        if (want_res) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                Rq[i] += conv[i] * pa + nu * visc[i] - p * ga[i] + (corrected ? tau * uga * r[i] : tau * u[i] * sa) +
+                         nuL * divu * ga[i];
+            Rq[3] += pa * divu + tau * sa;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += wd * blk[e];
+    if (want_res) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ra[c] += wd * Rq[c];
+    }
+}
+
+// off-diagonal BSR blocks: one lane per slot, slots taken from the host's count-sorted list
+template <bool corrected>
+__global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32_t* __restrict__ od_order,
+                                                       const int64_t* __restrict__ c_ptr,
+                                                       const int32_t* __restrict__ c_idx,
+                                                       const int32_t* __restrict__ slot_row,
+                                                       const int32_t* __restrict__ colind,
+                                                       const int32_t* __restrict__ tets,
+                                                       const double* __restrict__ pts, const double* __restrict__ w,
+                                                       const uint8_t* __restrict__ bc_mask, double nu,
+                                                       double* __restrict__ vals) {
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n_od) return;
+    const int64_t s = od_order[lane];
+    const int32_t row = slot_row[s], col = colind[s];
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    // the (contribution id -> tet nodes) loads of the NEXT contribution are issued before the current block is
+    // computed, so only the coordinate/state gather latency sits on the critical path
+    const int64_t k1 = c_ptr[s + 1];
+    int64_t k = c_ptr[s];
+    int32_t id = 0;
+    int4 tv = make_int4(0, 0, 0, 0);
+    if (k < k1) {
+        id = c_idx[k];
+        tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
+    }
+    while (k < k1) {
+        const int32_t idc = id;
+        const int4 tvc = tv;
+        if (++k < k1) {
+            id = c_idx[k];
+            tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
+        }
+        tet_block_accumulate<corrected>(tvc, pts, w, nu, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
+    }
+    const uchar4 mr = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)row);
+    const uchar4 mc = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)col);
+    const unsigned char rb[4] = {mr.x, mr.y, mr.z, mr.w}, cb[4] = {mc.x, mc.y, mc.z, mc.w};
+    double2* o = reinterpret_cast<double2*>(vals + 16 * s);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double v0 = (rb[c] | cb[0]) ? 0.0 : acc[4 * c], v1 = (rb[c] | cb[1]) ? 0.0 : acc[4 * c + 1];
+        const double v2 = (rb[c] | cb[2]) ? 0.0 : acc[4 * c + 2], v3 = (rb[c] | cb[3]) ? 0.0 : acc[4 * c + 3];
+        o[2 * c] = make_double2(v0, v1);
+        o[2 * c + 1] = make_double2(v2, v3);
+    }
+}
+
+// diagonal blocks + node residuals: 4 lanes per node share the ~24 incident tets, DPP quad sums in a fixed order
+template <bool corrected>
+__global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_t* __restrict__ diag,
+                                                    const int64_t* __restrict__ c_ptr,
+                                                    const int32_t* __restrict__ c_idx,
+                                                    const int32_t* __restrict__ tets, const double* __restrict__ pts,
+                                                    const double* __restrict__ w, const uint8_t* __restrict__ bc_mask,
+                                                    const double* __restrict__ bc_val, double nu,
+                                                    double* __restrict__ vals, double* __restrict__ F) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t node = gid >> 2;
+    const int q = (int)(gid & 3);
+    const bool live = node < n_rows;
+    double acc[16], R[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    int64_t s = 0;
+    if (live) {
+        s = diag[node];
+        const int64_t k1 = c_ptr[s + 1];
+        int64_t k = c_ptr[s] + q;
+        int32_t id = 0;
+        int4 tv = make_int4(0, 0, 0, 0);
+        if (k < k1) {
+            id = c_idx[k];
+            tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
+        }
+        while (k < k1) {
+            const int a = (id >> 2) & 3;
+            const int4 tvc = tv;
+            k += 4;
+            if (k < k1) {
+                id = c_idx[k];
+                tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
+            }
+            tet_block_accumulate<corrected>(tvc, pts, w, nu, a, a, true, acc, R);
+        }
+    }
+    // quad sums: (l0 + l1) + (l2 + l3), identical on every lane
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        double v = acc[e];
+        v += quad_perm<0xB1>(v);          // swap neighbours: [1,0,3,2]
+        v += quad_perm<0x4E>(v);          // swap pairs:      [2,3,0,1]
+        acc[e] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double v = R[c];
+        v += quad_perm<0xB1>(v);
+        v += quad_perm<0x4E>(v);
+        R[c] = v;
+    }
+    if (!live) return;
+    const uchar4 m4 = *reinterpret_cast<const uchar4*>(bc_mask + 4 * node);
+    const unsigned char mb[4] = {m4.x, m4.y, m4.z, m4.w};
+    // lane q writes row q of the block and component q of the residual
+    double row[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const double v = q == 0 ? acc[d] : (q == 1 ? acc[4 + d] : (q == 2 ? acc[8 + d] : acc[12 + d]));
+        const unsigned char rbq = q == 0 ? mb[0] : (q == 1 ? mb[1] : (q == 2 ? mb[2] : mb[3]));
+        row[d] = (rbq | mb[d]) ? ((q == d) ? 1.0 : 0.0) : v;
+    }
+    double2* o = reinterpret_cast<double2*>(vals + 16 * s + 4 * q);
+    o[0] = make_double2(row[0], row[1]);
+    o[1] = make_double2(row[2], row[3]);
+    if (F) {
+        const int64_t dof = 4 * node + q;
+        const double rq = q == 0 ? R[0] : (q == 1 ? R[1] : (q == 2 ? R[2] : R[3]));
+        F[dof] = bc_mask[dof] ? (w[dof] - bc_val[dof]) : rq;
+    }
+}
+#define SNS_INST_FUSED(C)                                                                                          \
+    template __global__ void k_fused_offdiag<C>(int64_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
+                                                const int32_t*, const int32_t*, const double*, const double*,       \
+                                                const uint8_t*, double, double*);                                   \
+    template __global__ void k_fused_diag<C>(int32_t, const int32_t*, const int64_t*, const int32_t*,               \
+                                             const int32_t*, const double*, const double*, const uint8_t*,          \
+                                             const double*, double, double*, double*);
+SNS_INST_FUSED(false)
+SNS_INST_FUSED(true)
+
 // Residual-only element pass for states that already satisfy the Dirichlet data (no lifting term):
 // ONE LANE PER TET, every lane busy (the fused kernel keeps 12 of 16 lanes idle in its per-point
 // phase).  Used by the line search (F(x - lambda y), :51-67 without the Jacobian).
@@ -568,15 +872,6 @@ __device__ __forceinline__ float4 ld_stream(const float4* p) {
 __device__ __forceinline__ double2 ld_stream(const double2* p) {
     const f64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f64x2_t*>(p));
     return make_double2(v.x, v.y);
-}
-
-// quad-permute a double with DPP moves (no LDS, no memory traffic); CTRL = quad_perm encoding
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {

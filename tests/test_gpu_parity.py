@@ -48,11 +48,19 @@ def test_element_kernel_against_golden_literal_forms(gpu):
         m = M.TetMesh(g["X"][i].copy(), np.array([[0, 1, 2, 3]], np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
         none = (np.zeros(16, np.uint8), np.zeros(16))
         for corrected, Fk, Jk in ((0, "F", "J"), (1, "F_corrected", "J_corrected")):
-            P = gpu(m, none, reynolds=float(g["Re"][i]), corrected_convection=corrected, pc_type="bjacobi")
+            P = gpu(m, none, reynolds=float(g["Re"][i]), corrected_convection=corrected, pc_type="bjacobi",
+                    assembly_fused=0)
             F = P.zeros()
             P.jacobian(_dev(g["W"][i].reshape(16)), "ns", residual_out=F)
             Ke = P.element_matrices().cpu().numpy()[0]            # [a,b,c,d]
             assert rel(Ke.transpose(0, 2, 1, 3).reshape(16, 16), g[Jk][i]) < 1e-12
+            assert rel(F.cpu().numpy(), g[Fk][i]) < 1e-12
+            P.close()
+            # scratch-free assembly (one lane per BSR block) on the same tet: the global matrix IS the element matrix
+            P = gpu(m, none, reynolds=float(g["Re"][i]), corrected_convection=corrected, pc_type="bjacobi")
+            F = P.zeros()
+            P.jacobian(_dev(g["W"][i].reshape(16)), "ns", residual_out=F)
+            assert rel(P.to_scipy().toarray(), g[Jk][i]) < 1e-12
             assert rel(F.cpu().numpy(), g[Fk][i]) < 1e-12
             P.close()
         P = gpu(m, none, pc_type="bjacobi")
@@ -511,13 +519,27 @@ def test_fast_residual_path_when_bcs_hold(gpu, corrected):
     w = np.random.default_rng(21).normal(size=m.num_dofs) * 0.5
     Bm = mask.astype(bool)
     w[Bm] = g[Bm]
-    P = gpu(m, (mask, g), reynolds=17.0, corrected_convection=corrected)
+    P = gpu(m, (mask, g), reynolds=17.0, corrected_convection=corrected, assembly_fused=0)
     F_fast = P.residual(_dev(w), "ns").cpu().numpy()            # fast path (no violations)
     F_fused = P.zeros()
-    P.jacobian(_dev(w), "ns", residual_out=F_fused)            # fused element kernel
+    P.jacobian(_dev(w), "ns", residual_out=F_fused)            # staged element kernel + gather
+    J_staged = P.to_scipy()
     assert rel(F_fast, F_fused.cpu().numpy()) < 1e-13
     if not corrected:
         assert rel(F_fast, asm.residual_ns(m.points, m.tets, w, 17.0, mask, g)) < 1e-12
+    # scratch-free assembly (block-owner lanes recompute their contributions) takes over for such states
+    P.set_options(assembly_fused=1)
+    F_sf = P.zeros()
+    P.jacobian(_dev(w), "ns", residual_out=F_sf)
+    J_sf = P.to_scipy()
+    assert abs(J_sf - J_staged).max() < 1e-13 * abs(J_staged).max()
+    assert rel(F_sf.cpu().numpy(), F_fast) < 1e-13
+    v1 = P.bsr()[2].clone()
+    P.jacobian(_dev(w), "ns", residual_out=F_sf)
+    assert torch.equal(v1, P.bsr()[2])                           # fixed summation order: bitwise reproducible
+    if not corrected:
+        Jo = asm.assemble_ns(m.points, m.tets, w, 17.0, mask, g)[0]
+        assert abs(J_sf - Jo).max() < 1e-12 * abs(Jo).max()
     w2 = w.copy(); w2[np.nonzero(Bm)[0][0]] += 0.3               # one violated dof -> general path with lifting
     if not corrected:
         assert rel(P.residual(_dev(w2), "ns").cpu().numpy(), asm.residual_ns(m.points, m.tets, w2, 17.0, mask, g)) < 1e-12
