@@ -10,7 +10,8 @@ When the sequence converges (||F|| < 1e-8, :281) it restarts from the Stokes sol
 metric = M-DOF/s = N_dof / (t_assemble + t_solve) per Newton iteration / 1e6  (SURVEY 8d).
 
   python bench.py [--gpus N --steps K --warmup W]           (N>1 under torch.distributed.run)
-N>1: the SAME mesh is element-partitioned over the ranks (strong scaling), halo exchange
+N>1 (weak scaling): the duct is refined by N^(1/3) per direction, every GPU keeps a ~10.1 M-tet x-slab
+(--strong: the SAME mesh is element-partitioned over the ranks instead), halo exchange
 and dot-product all-reduces on RCCL inside libsns.so.
 """
 import argparse
@@ -88,9 +89,14 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=str, default="300,75,75")
+    ap.add_argument("--length", type=float, default=4.0, help="duct length of the single-GPU share")
     ap.add_argument("--re", type=float, default=200.0)
     ap.add_argument("--ksp", type=str, default="bicgstab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: partition the SAME --cells mesh over the ranks instead of refining the duct with N")
     args = ap.parse_args()
 
     import torch
@@ -113,14 +119,33 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     cells = tuple(int(c) for c in args.cells.split(","))
-    mesh = M.duct_mesh(cells, 4.0)
-    bcs = B.duct_bcs(mesh)
     opts = dict(reynolds=args.re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
-    if world > 1 or force_dist:
-        P = FlowProblem.distributed(mesh, bcs, device=f"cuda:{local_rank}", **opts)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
+    weak = world > 1 and not args.strong
+    if weak:
+        # weak scaling: the duct is refined uniformly so that every GPU keeps about the single-GPU share
+        # (--cells tets): cells x N^(1/3) per direction, same geometry and Re.  Ranks own x-slabs; each rank
+        # meshes only its own slab (+ one ghost cell layer), never the global mesh.
+        from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
+        sc = float(world) ** (1.0 / 3.0)
+        cells = tuple(int(round(c * sc)) for c in cells)
+        length = args.length
+        part = PT.duct_slab_part(cells, length, rank, world)
+        P = FlowProblem.from_part(part, device=f"cuda:{local_rank}", **opts)
+        n_dof_global = 4 * (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+        n_tets_global = 6 * cells[0] * cells[1] * cells[2]
     else:
-        P = FlowProblem(mesh, bcs, device=f"cuda:{local_rank}", **opts)
-    n_dof_global = mesh.num_dofs
+        length = args.length
+        mesh = M.duct_mesh(cells, length)
+        bcs = B.duct_bcs(mesh)
+        if world > 1 or force_dist:
+            P = FlowProblem.distributed(mesh, bcs, device=f"cuda:{local_rank}", **opts)
+        else:
+            P = FlowProblem(mesh, bcs, device=f"cuda:{local_rank}", **opts)
+        n_dof_global = mesh.num_dofs
+        n_tets_global = mesh.num_tets
     U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
     if sres.reason <= 0:
         raise RuntimeError(f"Stokes solve did not converge: {sres}")
@@ -189,15 +214,16 @@ def main():
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "precision_note": "operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "
                           "smoother/residual passes read an fp32 copy of the level matrices (arithmetic f64)"
                           if P.options.amg_f32_matrix else "all f64",
-        "config": {"workload": f"duct {cells[0]}x{cells[1]}x{cells[2]} cells = {mesh.num_tets} tets, "
+        "config": {"workload": f"duct [0,{length:g}]x[-.5,.5]^2, {cells[0]}x{cells[1]}x{cells[2]} cells = {n_tets_global} tets, "
                                f"{n_dof_global} dofs, Re={args.re:g}, Newton iteration (assemble J+F, AMG setup, "
                                f"{args.ksp} rtol 1e-8, bt line search)",
-                   "parallelism": f"element-partitioned x{world}" if world > 1 else "single GPU",
+                   "parallelism": (f"x-slab element partition x{world}, {n_tets_global // world} tets per GPU"
+                                   if world > 1 else "single GPU"),
                    "newton_log_fnorm_kspits_reason": [(float(f"{a:.3e}"), b, c) for a, b, c in log],
                    "phase_ms_per_step": {"assemble": round(tm.assemble_ms / args.steps, 3),
                                          "pc_setup": round(tm.pc_setup_ms / args.steps, 3),

@@ -74,7 +74,7 @@ _KUHN = np.stack(_KUHN)               # (6,4,3)
 
 
 def box_tet_mesh(lo, hi, cells, *, jitter: float = 0.0, seed: int = 1234,
-                 name: str = "box") -> tuple[np.ndarray, np.ndarray, tuple]:
+                 name: str = "box", x_window=None) -> tuple[np.ndarray, np.ndarray, tuple]:
     """Nodes and Kuhn-6 tets of the box ``lo..hi`` with ``cells=(nx,ny,nz)``.
 
     Node id = (i*(ny+1) + j)*(nz+1) + k  (x slowest), so that slabs in x are
@@ -82,11 +82,22 @@ def box_tet_mesh(lo, hi, cells, *, jitter: float = 0.0, seed: int = 1234,
     neighbours of a node live in three adjacent yz-planes (SpMV locality).
     Optional interior-node jitter (+-jitter*h) breaks structured
     cache luck; boundary nodes never move.
+    ``x_window=(c0, c1)`` returns only the cell planes c0 <= i < c1 (node planes c0..c1, coordinates
+    bit-identical to the full box; window node id = global id - c0*(ny+1)*(nz+1)): one rank's piece of
+    a slab-partitioned run is meshed without ever building the global mesh.
     """
     nx, ny, nz = (int(c) for c in cells)
     lo = np.asarray(lo, dtype=np.float64)
     hi = np.asarray(hi, dtype=np.float64)
     xs = np.linspace(lo[0], hi[0], nx + 1)
+    if x_window is not None:
+        c0, c1 = int(x_window[0]), int(x_window[1])
+        if not (0 <= c0 < c1 <= nx):
+            raise ValueError(f"x_window {x_window} outside 0..{nx}")
+        if jitter > 0.0:
+            raise ValueError("jitter is not supported on a window of the box")
+        xs = xs[c0:c1 + 1]
+        nx = c1 - c0
     ys = np.linspace(lo[1], hi[1], ny + 1)
     zs = np.linspace(lo[2], hi[2], nz + 1)
     X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
@@ -133,12 +144,24 @@ def _tag_box_facets(pts, facets, lo, hi, tagger) -> np.ndarray:
 
 
 def duct_mesh(cells=(40, 10, 10), x_outlet: float = 4.0, *, jitter: float = 0.0,
-              tags: dict | None = None) -> TetMesh:
-    """Square duct [0,x_outlet] x [-.5,.5]^2 (DuctStokesFlow.py:36-124)."""
+              tags: dict | None = None, x_window=None) -> TetMesh:
+    """Square duct [0,x_outlet] x [-.5,.5]^2 (DuctStokesFlow.py:36-124).
+
+    With ``x_window=(c0, c1)`` only that range of cell planes is meshed (see box_tet_mesh); the cut
+    planes are interior, so they carry no boundary facets."""
     tags = dict(DUCT_TAGS if tags is None else tags)
     lo, hi = (0.0, -0.5, -0.5), (float(x_outlet), 0.5, 0.5)
-    pts, tets, _ = box_tet_mesh(lo, hi, cells, jitter=jitter)
+    pts, tets, _ = box_tet_mesh(lo, hi, cells, jitter=jitter, x_window=x_window)
     fac = _boundary_facets(tets)
+    if x_window is not None:
+        sx = (int(cells[1]) + 1) * (int(cells[2]) + 1)
+        plane = fac // sx
+        cut = np.zeros(len(fac), dtype=bool)
+        if x_window[0] > 0:
+            cut |= np.all(plane == 0, axis=1)
+        if x_window[1] < int(cells[0]):
+            cut |= np.all(plane == x_window[1] - x_window[0], axis=1)
+        fac = fac[~cut]
 
     def tagger(on, _cent):
         t = np.full(fac.shape[0], tags["wall"])
@@ -147,8 +170,10 @@ def duct_mesh(cells=(40, 10, 10), x_outlet: float = 4.0, *, jitter: float = 0.0,
         return t
 
     ft = _tag_box_facets(pts, fac, lo, hi, tagger)
-    return TetMesh(pts, tets, fac, ft, name="duct",
-                   meta={"cells": tuple(cells), "lo": lo, "hi": hi, "tags": tags, "kind": "duct"})
+    meta = {"cells": tuple(cells), "lo": lo, "hi": hi, "tags": tags, "kind": "duct"}
+    if x_window is not None:
+        meta["x_window"] = (int(x_window[0]), int(x_window[1]))
+    return TetMesh(pts, tets, fac, ft, name="duct", meta=meta)
 
 
 def channel_mesh(cells=(40, 10, 10), *, inner_half_width: float = 0.25, jitter: float = 0.0) -> TetMesh:

@@ -42,6 +42,62 @@ def rcb_partition(points: np.ndarray, nparts: int) -> np.ndarray:
     return owner
 
 
+def slab_bounds(n_nodes: int, nparts: int) -> np.ndarray:
+    """Node-id ranges [b[r], b[r+1]) that rcb_partition produces when every bisection cuts the SAME axis
+    and node ids ascend along it (box meshes: x slowest): the recursion on counts alone."""
+    b = np.zeros(int(nparts) + 1, dtype=np.int64)
+
+    def rec(a, e, lo, k):
+        if k == 1:
+            b[lo], b[lo + 1] = a, e
+            return
+        kl = k // 2
+        nl = ((e - a) * kl) // k
+        rec(a, a + nl, lo, kl)
+        rec(a + nl, e, lo + kl, k - kl)
+
+    rec(0, int(n_nodes), 0, int(nparts))
+    return b
+
+
+def slab_owner(n_nodes: int, nparts: int, ids=None) -> np.ndarray:
+    """owner[node] for the x-slab partition (equal node counts, contiguous id ranges)."""
+    ids = np.arange(n_nodes, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+    return (np.searchsorted(slab_bounds(n_nodes, nparts), ids, side="right") - 1).astype(np.int32)
+
+
+def duct_slab_part(cells, x_outlet: float, rank: int, nranks: int, make_bcs=None) -> "LocalPart":
+    """One rank's LocalPart of the structured duct WITHOUT building the global mesh (weak-scaling runs:
+    the global mesh of an 8-GPU job has 81 M tets, every rank would otherwise mesh and partition all of it).
+
+    Identical (ids, ordering, plans, coordinates, Dirichlet data) to
+    ``build_local_part(duct_mesh(cells, x_outlet), ..., slab_owner(n_nodes, nranks), rank, nranks)``;
+    slab_owner equals rcb_partition while every slab is longer than the duct is wide (RCB then cuts x only)."""
+    from . import bcs as B, mesh as M
+    nx, ny, nz = (int(c) for c in cells)
+    sx = (ny + 1) * (nz + 1)
+    n_nodes = (nx + 1) * sx
+    bounds = slab_bounds(n_nodes, nranks)
+    if np.any(np.diff(bounds) < 2 * sx):
+        raise ValueError("duct_slab_part: fewer than two node planes per rank")
+    b0, b1 = int(bounds[rank]), int(bounds[rank + 1])
+    if b1 <= b0:
+        raise ValueError("duct_slab_part: empty slab")
+    p0, p1 = b0 // sx, (b1 - 1) // sx                   # first / last node plane holding an owned node
+    c0, c1 = max(0, p0 - 1), min(nx, p1 + 1)            # cells touching those planes
+    win = M.duct_mesh((nx, ny, nz), x_outlet, x_window=(c0, c1))
+    off = c0 * sx
+    gid = np.arange(win.num_nodes, dtype=np.int64) + off
+    owner = slab_owner(n_nodes, nranks, gid)
+    mask, g = (make_bcs or B.duct_bcs)(win).flatten()
+    part = build_local_part(win, mask, g, owner, rank, nranks)
+    part.l2g = part.l2g + off
+    part.tet_ids = part.tet_ids + 6 * c0 * ny * nz
+    part.mesh.meta["global_cells"] = (nx, ny, nz)
+    part.mesh.meta["global_num_nodes"] = n_nodes
+    return part
+
+
 @dataclass
 class LocalPart:
     """One rank's share.  Local node numbering: owned nodes first (ascending

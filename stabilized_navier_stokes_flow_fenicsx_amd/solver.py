@@ -108,6 +108,17 @@ class FlowProblem:
         self.global_mesh = mesh
         return self
 
+    @classmethod
+    def from_part(cls, part, *, group=None, device=None, **kw):
+        """One rank's problem from a ready-made LocalPart (e.g. partition.duct_slab_part, which meshes only
+        this rank's slab); same communicator bootstrap as ``distributed``."""
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}"
+        self = cls(part.mesh, (part.bc_mask, part.bc_val), device=device, part=part, group=group, **kw)
+        self.global_mesh = None
+        self.n_global_nodes = int(part.mesh.meta.get("global_num_nodes", 0))
+        return self
+
     def _attach_comm(self, part, group):
         nb = np.ascontiguousarray(part.neighbors, dtype=np.int32)
         sp_, si = np.ascontiguousarray(part.send_ptr, np.int32), np.ascontiguousarray(part.send_idx, np.int32)
@@ -151,7 +162,8 @@ class FlowProblem:
             out = torch.zeros(4 * len(self.part.l2g), dtype=x_local.dtype, device=x_local.device)
             out.view(-1, 4)[torch.as_tensor(self.part.l2g, device=x_local.device)] = x_local.view(-1, 4)
             return out
-        return PT.gather_owned(self.part, x_local, self.global_mesh.num_nodes, self.group)
+        ng = self.global_mesh.num_nodes if self.global_mesh is not None else self.n_global_nodes
+        return PT.gather_owned(self.part, x_local, ng, self.group)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):

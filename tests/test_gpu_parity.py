@@ -370,7 +370,7 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     assert nres.reason > 0 and msh.num_tets == 6 ** 4
 
 
-@pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity")])
+@pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab")])
 def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
     exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
@@ -379,6 +379,9 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
     if kind == "duct":
         m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
+        mask, g = B.duct_bcs(m).flatten()
+    elif kind == "slab":                            # bench.py's weak-scaling layout: thin x-slabs, each rank meshes its own
+        m = M.duct_mesh((36, 8, 8), 4.0)
         mask, g = B.duct_bcs(m).flatten()
     else:                                           # 2 x 2 RCB blocks: up to 3 neighbours per rank, corner ghosts
         m = M.cavity_mesh(12, jitter=0.1)
@@ -393,8 +396,12 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     team = Team(nranks)
 
     def work(rank, team):
-        part = PT.build_local_part(m, mask, g, owner, rank, nranks)
-        P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
+        if kind == "slab":
+            P = gpu.from_part(PT.duct_slab_part((36, 8, 8), 4.0, rank, nranks), group=team, reynolds=Re)
+            part = P.part
+        else:
+            part = PT.build_local_part(m, mask, g, owner, rank, nranks)
+            P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
         U, r = P.stokes_solve()
         w, n = P.newton_solve(U.clone())
         out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n)
