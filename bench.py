@@ -69,19 +69,21 @@ def pmc_traffic(kernel_substr="k_spmv<2, 1"):
     FETCH_SIZE is in KiB and reads half the bytes of a wide streaming read on gfx950 (x2);
     WRITE_SIZE (KiB) is exact.  None if no such profile is committed."""
     import csv
-    tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
-    for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc*counter_collection.csv")):
+    fetch = write = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*counter_collection.csv"))):   # latest round wins
+        tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") in tot:
                     tot[row["Counter_Name"]][0] += float(row["Counter_Value"])
                     tot[row["Counter_Name"]][1] += 1
-    if not (tot["FETCH_SIZE"][1] and tot["WRITE_SIZE"][1]):
+        if tot["FETCH_SIZE"][1]:
+            fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] * 1024.0 * 2.0
+        if tot["WRITE_SIZE"][1]:
+            write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] * 1024.0
+    if fetch is None or write is None:
         return None
-    fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] * 1024.0 * 2.0
-    write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] * 1024.0
     return fetch + write
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -192,6 +194,9 @@ def main():
     tm = P.timings()
     kt = P.kernel_times()
     s = P.sizes()
+    # K1 (Jacobian + residual assembly) timed on its own after the timed region: HIP events around 5 passes
+    asm_ms = P.bench_assemble(w, "ns", 5)
+    asm_bytes = 2480.0 * s["n_tets"]                   # 2480 B/tet
     # dominant kernel: the level-0 block-Jacobi sweep of the AMG cycle (3 of the 5 fine-level matrix passes
     # per preconditioner application).  Algorithmic bytes per launch:
     #   per nonzero block: values (64 B as the preconditioner's fp32 copy, 128 B in fp64) + 4 B column index
@@ -209,6 +214,11 @@ def main():
                     "traffic": pmc_traffic("k_spmv_f32<2, 1" if f32 else "k_spmv<2, 1"),
                     "kernel": kname, "avg_launch_ms": round(avg_ms, 5),
                     "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
+                    "assembly_kernels": {"avg_ms": round(asm_ms, 4), "algorithmic_bytes": asm_bytes,
+                                         "achieved": round(asm_bytes / (asm_ms * 1e-3) / 1e9, 1),
+                                         "frac": round(asm_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "path": "scratch-free (k_fused_offdiag + k_fused_diag)"
+                                                 if P.options.assembly_fused else "staged (k_element + gathers)"},
                     "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}
                                         for k, v in kt.items() if v[1] > 0 and k != "jacobi"}}
     out = {
