@@ -237,3 +237,34 @@ def test_tet_face_adjacency():
                 assert (set(m.tets[t]) - {m.tets[t, a]}).issubset(set(m.tets[u])) and t in nb[u]
     s = make_rev_streamtrace_seeds(-0.2, 0.3, -0.1, 0.1, 5)
     assert s.shape == (25, 3) and np.all(s[:, 0] == 3.9)                             # streamtrace.py:346-355
+
+
+def test_boundary_traction_force_known_answers_and_oracle():
+    """Drag/lift functional (DFG_3D_Validation.py:344-367): exact for P1 fields; Couette + hydrostatic known
+    answers on the duct wall, and the facet-by-facet oracle on a jittered mesh with a random field."""
+    from oracle.functionals import traction_force_loops
+    from stabilized_navier_stokes_flow_fenicsx_amd import functionals as Fn, mesh as M
+    m = M.duct_mesh((6, 3, 3), 4.0)
+    x, y, z = m.points.T
+    nu = 0.37
+    w = np.zeros((m.num_nodes, 4))
+    w[:, 0] = y                                   # Couette u = (y,0,0): sym grad u has only xy = 1/2
+    w[:, 3] = 2.5                                 # constant pressure
+    t = m.meta["tags"]
+    # wall = 4 faces y,z = +-0.5, each of area 4; n = -(outward):  y=+.5: n=(0,-1,0) -> traction (-nu, +p, 0)
+    # y=-.5: n=(0,1,0) -> (nu, -p, 0); z faces: n=(0,0,-+1) -> (0,0,+-p): sum = 0.  Closed surface pieces cancel:
+    f = Fn.boundary_traction_force(m, w.ravel(), nu, t["wall"])
+    assert np.allclose(f, 0.0, atol=1e-12)
+    # inlet face x = 0 (area 1): outward = (-1,0,0), n = (1,0,0): traction = (-p, nu*1, 0)
+    f = Fn.boundary_traction_force(m, w.ravel(), nu, t["inlet"])
+    assert np.allclose(f, [-2.5, nu, 0.0], atol=1e-12)
+    cd, cl = Fn.drag_lift_coefficients(f)
+    assert np.isclose(cd, 2 * -2.5 / (0.2 ** 2 * 0.041)) and np.isclose(cl, 2 * nu / (0.2 ** 2 * 0.041))
+    # linear pressure p = 3 - x on the outlet x = 4: n = (-1,0,0): traction_x = +p = -1
+    w2 = np.zeros((m.num_nodes, 4)); w2[:, 3] = 3.0 - x
+    assert np.allclose(Fn.boundary_traction_force(m, w2.ravel(), nu, t["outlet"]), [-1.0, 0, 0], atol=1e-12)
+    mj = M.duct_mesh((4, 2, 3), 4.0, jitter=0.2)
+    wr = np.random.default_rng(5).normal(size=mj.num_dofs)
+    for tag in (t["wall"], t["inlet"]):
+        ref = traction_force_loops(mj.points, mj.tets, mj.facets, mj.find(tag), wr, nu)
+        assert np.allclose(Fn.boundary_traction_force(mj, wr, nu, tag), ref, rtol=1e-12, atol=1e-12)
