@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--re", type=float, default=200.0)
     ap.add_argument("--ksp", type=str, default="bicgstab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-rerun", action="store_true", help="skip the all-fp64 repetition of the timed steps")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
     ap.add_argument("--strong", action="store_true",
@@ -197,6 +198,31 @@ def main():
     # K1 (Jacobian + residual assembly) timed on its own after the timed region: HIP events around 5 passes
     asm_ms = P.bench_assemble(w, "ns", 5)
     asm_bytes = 2480.0 * s["n_tets"]                   # 2480 B/tet
+    # the same K steps once more with EVERY array in fp64 (no fp32 copies inside the preconditioner), reported
+    # beside the headline so that the effect of the mixed-precision preconditioner is on record
+    all_f64 = None
+    if P.options.amg_f32_matrix and not args.no_f64_rerun:
+        main_log = list(log)
+        P.set_options(amg_f32_matrix=0)
+        w, seq = U.clone(), 0
+        for _ in range(args.warmup):
+            step()
+        log.clear()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt64 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt64], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt64 = float(t)
+        ms64 = dt64 / max(1, args.steps) * 1e3
+        all_f64 = {"value": round(n_dof_global / (ms64 * 1e-3) / 1e6, 3), "unit": "M-DOF/s", "ms_per_step": round(ms64, 3),
+                   "ksp_its": [b for _, b, _ in log]}
+        P.set_options(amg_f32_matrix=1)
+        log[:] = main_log
     # dominant kernel: the level-0 block-Jacobi sweep of the AMG cycle (3 of the 5 fine-level matrix passes
     # per preconditioner application).  Algorithmic bytes per launch:
     #   per nonzero block: values (64 B as the preconditioner's fp32 copy, 128 B in fp64) + 4 B column index
@@ -218,7 +244,15 @@ def main():
                                          "achieved": round(asm_bytes / (asm_ms * 1e-3) / 1e9, 1),
                                          "frac": round(asm_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "path": "scratch-free (k_fused_offdiag + k_fused_diag)"
-                                                 if P.options.assembly_fused else "staged (k_element + gathers)"},
+                                                 if P.options.assembly_fused else "staged (k_element + gathers)",
+                                         # secondary: executed fp64 VALU flops of the scratch-free path,
+                                         # counted from the gfx950 ISA: 300 fmac + 82 fma + 244 mul + 97 add per
+                                         # block contribution = 1105 flop, 16 contributions per tet
+                                         "fp64_vector": ({"executed_flops_per_tet": 17680,
+                                                          "achieved_tflops": round(17680.0 * s["n_tets"] / (asm_ms * 1e-3) / 1e12, 2),
+                                                          "peak_tflops": 78.6,
+                                                          "frac": round(17680.0 * s["n_tets"] / (asm_ms * 1e-3) / 1e12 / 78.6, 4)}
+                                                         if P.options.assembly_fused else None)},
                     "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}
                                         for k, v in kt.items() if v[1] > 0 and k != "jacobi"}}
     out = {
@@ -240,6 +274,7 @@ def main():
                                          "krylov": round(tm.krylov_ms / args.steps, 3)},
                    "amg_levels": tm.amg_levels, "stokes_its": sres.its},
         "roofline": roofline,
+        "all_f64_preconditioner": all_f64,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -7,7 +7,7 @@ for spec in sys.argv[2:]:
     for kv in spec.split(","):
         if kv:
             extra += ["--opt", kv]
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "3"] + common + extra,
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "3", "--no-f64-rerun"] + common + extra,
                          capture_output=True, text=True)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])

@@ -7,11 +7,11 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 python bench.py > $out/${tag}_bench_unprofiled.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f64-rerun > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/fetch.json 2> $out/fetch.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f64-rerun > $out/fetch.json 2> $out/fetch.err
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/write.json 2> $out/write.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f64-rerun > $out/write.json 2> $out/write.err
 echo "write done"
 cd $R
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv

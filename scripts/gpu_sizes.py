@@ -3,7 +3,7 @@ import sys, os, subprocess, json
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for spec in sys.argv[1:]:
     cells, length = spec.split(":")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "3", "--cells", cells,
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-f64-rerun", "--steps", "3", "--cells", cells,
                           "--length", length], capture_output=True, text=True)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])
