@@ -898,23 +898,44 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
     double acc0 = 0.0, acc1 = 0.0;
     const bool live = row < n_rows;
     {
-        // the 8 lanes of a row share the trip count, so each quad is uniform: lane j of a quad fetches
-        // component j of the x block (8 B) and the pair (2*hf, 2*hf+1) it needs arrives by DPP
+        // The kernel is bound by VMEM instruction issue, not by bytes, so every step of 4 blocks issues as few
+        // loads as possible: ONE index load per quad (lane j fetches colind[k + j]; DPP hands the ids round),
+        // FOUR 16-B matrix loads, and TWO 16-B x loads (quad lane j fetches half (j & 1) of the x block of
+        // column k + (j >> 1), then of column k + 2 + (j >> 1)); the pair (2*hf, 2*hf+1) a lane needs arrives
+        // by DPP.  7 VMEM instructions per step instead of 12.  The last step of a row is masked (zero matrix
+        // values, clamped index) instead of a scalar tail: a 15-block row takes 4 memory round trips, not 6.
         const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
         const int jq = lane & 3;
         const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals) + ((int64_t)s * 8 + r * 2 + hf);
         int32_t k = s;
-        for (; k + 3 < e; k += 4) {
-            const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
-            const double2 a0 = (NT ? ld_stream(vp) : vp[0]), a1 = (NT ? ld_stream(vp + 8) : vp[8]),
-                          a2 = (NT ? ld_stream(vp + 16) : vp[16]), a3 = (NT ? ld_stream(vp + 24) : vp[24]);
-            const double g0 = x[4 * (int64_t)c0 + jq], g1 = x[4 * (int64_t)c1 + jq];
-            const double g2 = x[4 * (int64_t)c2 + jq], g3 = x[4 * (int64_t)c3 + jq];
-            acc0 += a0.x * quad_perm<0x88>(g0) + a0.y * quad_perm<0xDD>(g0);
-            acc1 += a1.x * quad_perm<0x88>(g1) + a1.y * quad_perm<0xDD>(g1);
-            acc0 += a2.x * quad_perm<0x88>(g2) + a2.y * quad_perm<0xDD>(g2);
-            acc1 += a3.x * quad_perm<0x88>(g3) + a3.y * quad_perm<0xDD>(g3);
-            vp += 32;
+        if (NT == 2) {          // harness variant: r1e loop (4 broadcast index loads, 8-B x loads, scalar tail), nt stream
+            for (; k + 3 < e; k += 4) {
+                const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
+                const double2 a0 = ld_stream(vp), a1 = ld_stream(vp + 8), a2 = ld_stream(vp + 16), a3 = ld_stream(vp + 24);
+                const double g0 = x[4 * (int64_t)c0 + jq], g1 = x[4 * (int64_t)c1 + jq];
+                const double g2 = x[4 * (int64_t)c2 + jq], g3 = x[4 * (int64_t)c3 + jq];
+                acc0 += a0.x * quad_perm<0x88>(g0) + a0.y * quad_perm<0xDD>(g0);
+                acc1 += a1.x * quad_perm<0x88>(g1) + a1.y * quad_perm<0xDD>(g1);
+                acc0 += a2.x * quad_perm<0x88>(g2) + a2.y * quad_perm<0xDD>(g2);
+                acc1 += a3.x * quad_perm<0x88>(g3) + a3.y * quad_perm<0xDD>(g3);
+                vp += 32;
+            }
+        } else {
+            for (; k + 3 < e; k += 4) {
+                const int32_t cme = colind[k + jq];
+                const double2 a0 = (NT ? ld_stream(vp) : vp[0]), a1 = (NT ? ld_stream(vp + 8) : vp[8]),
+                              a2 = (NT ? ld_stream(vp + 16) : vp[16]), a3 = (NT ? ld_stream(vp + 24) : vp[24]);
+                const int32_t cA = __builtin_amdgcn_mov_dpp(cme, 0x50, 0xF, 0xF, true);      // ids of blocks [0,0,1,1]
+                const int32_t cB = __builtin_amdgcn_mov_dpp(cme, 0xFA, 0xF, 0xF, true);      // ids of blocks [2,2,3,3]
+                const double2 gA = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cA + 2 * (jq & 1));
+                const double2 gB = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cB + 2 * (jq & 1));
+                // lane (.., hf) takes its pair from quad lane hf (block 0 / 2) or 2 + hf (block 1 / 3)
+                acc0 += a0.x * quad_perm<0x44>(gA.x) + a0.y * quad_perm<0x44>(gA.y);
+                acc1 += a1.x * quad_perm<0xEE>(gA.x) + a1.y * quad_perm<0xEE>(gA.y);
+                acc0 += a2.x * quad_perm<0x44>(gB.x) + a2.y * quad_perm<0x44>(gB.y);
+                acc1 += a3.x * quad_perm<0xEE>(gB.x) + a3.y * quad_perm<0xEE>(gB.y);
+                vp += 32;
+            }
         }
         for (; k < e; ++k) {
             const double2 a0 = (NT ? ld_stream(vp) : vp[0]);
@@ -962,6 +983,7 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
                                              double*, const double*, const double*, double, const double*, double*);
 SNS_INST_SPMV(SPMV_AX, 1, 1)
 SNS_INST_SPMV(SPMV_AX, 1, 0)
+SNS_INST_SPMV(SPMV_AX, 1, 2)
 SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1)
 SNS_INST_SPMV(SPMV_JACOBI, 1, 1)
 SNS_INST_SPMV(SPMV_AX_DOT, 1, 1)
@@ -976,6 +998,8 @@ SNS_INST_SPMV(SPMV_JACOBI, 0, 0)
 // broadcast lane J of every quad (4 consecutive lanes)
 template <int J>
 __device__ __forceinline__ double quad_bcast(double v) { return quad_perm<J * 0x55>(v); }
+template <int J>
+__device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true); }
 
 template <int MODE, int FINE, int NT>
 __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t* __restrict__ rowptr,
@@ -993,12 +1017,21 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
     const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The kernel is bound by VMEM issue (cache lines touched per instruction), not by bytes.  Per quad and step of
+    // 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids round) instead of four
+    // broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches component r of each x block).
+    // NT selects experiment variants for the interleaved A/B harness (sns_bench_variants); 0 is production.
     int32_t k = s;
     for (; k + 3 < e; k += 4) {
-        const int32_t c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
-        const float4 a0 = vp[0], a1 = vp[4],
-                     a2 = vp[8], a3 = vp[12];
-        // lane r fetches component r of each x block (8 B); the quad shares them through DPP
+        int32_t c0, c1, c2, c3;
+        if (NT == 2) {
+            c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
+        } else {
+            const int32_t cme = colind[k + r];
+            c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
+        }
+        const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
         const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
         const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
         acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
@@ -1011,12 +1044,30 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
                 (double)a3.w * quad_bcast<3>(g3);
         vp += 16;
     }
-    for (; k < e; ++k) {
-        const float4 a0 = vp[0];
-        const double g0 = x[4 * (int64_t)colind[k] + r];
-        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                (double)a0.w * quad_bcast<3>(g0);
-        vp += 4;
+    if (NT == 1) {
+        if (k < e) {                                 // variant: a row's last 1..3 blocks in one masked step
+            const int rem = e - k;
+            const int32_t cme = colind[k + (r < rem ? r : rem - 1)];
+            const int32_t c0 = quad_bcast_i<0>(cme), c1 = quad_bcast_i<1>(cme), c2 = quad_bcast_i<2>(cme);
+            const float4 a0 = vp[0];
+            const float4 a1 = rem > 1 ? vp[4] : z4;
+            const float4 a2 = rem > 2 ? vp[8] : z4;
+            const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r], g2 = x[4 * (int64_t)c2 + r];
+            acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                    (double)a0.w * quad_bcast<3>(g0);
+            acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
+                    (double)a1.w * quad_bcast<3>(g1);
+            acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
+                    (double)a2.w * quad_bcast<3>(g2);
+        }
+    } else {
+        for (; k < e; ++k) {
+            const float4 a0 = vp[0];
+            const double g0 = x[4 * (int64_t)colind[k] + r];
+            acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                    (double)a0.w * quad_bcast<3>(g0);
+            vp += 4;
+        }
     }
     const double acc = acc0 + acc1;                 // (A x)[4*row + r]
     if (MODE == SPMV_B_MINUS_AX) {
@@ -1026,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
         const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
         if (live) {
             const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
-            const double2 d01 = NT ? ld_stream(D2) : D2[0], d23 = NT ? ld_stream(D2 + 1) : D2[1];
+            const double2 d01 = D2[0], d23 = D2[1];
             y[4 * (int64_t)row + r] =
                 x[4 * (int64_t)row + r] + omega * (d01.x * r0 + d01.y * r1 + d23.x * r2 + d23.y * r3);
         }
@@ -1038,6 +1089,7 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
 SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0)
 SNS_INST_SPMV32(SPMV_JACOBI, 1, 0)
 SNS_INST_SPMV32(SPMV_JACOBI, 1, 1)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 2)
 SNS_INST_SPMV32(SPMV_B_MINUS_AX, 0, 0)
 SNS_INST_SPMV32(SPMV_JACOBI, 0, 0)
 
