@@ -97,7 +97,8 @@ struct sns_ctx {
     bool graph_disabled = false;
     int matrix_form = -1;
     // reductions
-    double* partial = nullptr;                   // [2048*8]
+    double* partial = nullptr;                   // [max(65536*8, n/32)]
+    double* partial2 = nullptr;                  // second stage of long reductions
     double* d_scal = nullptr;                    // [256]
     double* h_scal = nullptr;                    // pinned [256]
     // Krylov workspace
@@ -171,6 +172,17 @@ void time_collect(sns_ctx* h) {
 
 // finish a two-stage reduction locally: partial[nblocks][nred] -> dst_dev[0..nred)
 void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
+    if (nblocks > 8192 && nred <= 8) {
+        // the fused SpMV+dot leaves one partial per 32 rows (54 k at 10 M tets): a single workgroup needs ~40 us
+        // for that, 2048-wide chunks on many CUs first ~5 us
+        const int nchunks = (nblocks + 2047) / 2048;
+        if (nchunks <= 4096) {
+            hipLaunchKernelGGL(k_reduce_chunks, dim3(nchunks, nred), dim3(256), 0, h->stream, nblocks, nred, h->partial,
+                               h->partial2);
+            hipLaunchKernelGGL(k_reduce_final, dim3(nred), dim3(256), 0, h->stream, nchunks, nred, h->partial2, dst_dev);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_reduce_final, dim3(nred), dim3(256), 0, h->stream, nblocks, nred, h->partial, dst_dev);
 }
 // sum `count` device doubles over the ranks (no-op without a communicator)
@@ -308,7 +320,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         if (flag[0] == 0.0) break;
         std::vector<int32_t> agg;
         int32_t nc_owned = 0;
-        aggregate_nodes(cur, n_owned, std::max(2, o.amg_agg_size), agg, nc_owned);
+        aggregate_nodes(cur, n_owned, std::min(255, std::max(2, o.amg_agg_size)), agg, nc_owned);
         double prog[2] = {(double)n_owned, (double)nc_owned};
         SNS_TRY(global_sum(h, prog, 2));
         if (prog[1] >= prog[0] || prog[1] == 0.0) break;      // no progress anywhere
@@ -620,10 +632,10 @@ int pc_setup(sns_ctx* h) {
         }
         if (l + 1 < nl) {
             Level& C = h->levels[l + 1];
-            const int64_t nth = C.nnzb * 16;
+            const int64_t nth = C.nnzb * 8;
             hipLaunchKernelGGL(k_galerkin, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, C.nnzb,
-                               L.r_ptr, L.r_idx, h->slot_row[l], L.colind, L.free_mask, L.vals, h->slot_row[l + 1],
-                               C.colind, (l == 0) ? h->empty_c[0] : (const uint8_t*)nullptr, C.vals);
+                               L.r_ptr, L.r_idx, L.vals, h->slot_row[l + 1], C.colind,
+                               (l == 0) ? h->empty_c[0] : (const uint8_t*)nullptr, L.m_ptr, C.vals);
         } else if (h->cg_N > 0 && nl > 1) {
             // distributed coarsest level: my rows of the GLOBAL dense matrix -> all-gather -> replicated inverse
             const int N = h->cg_N, mr = 4 * h->cg_maxn;
@@ -1287,7 +1299,9 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
         for (size_t i = 0; i < fm.size(); ++i) fm[i] = bc_mask[i] ? 0 : 1;
         SNS_TRY(dev_upload(&h->levels[0].free_mask, fm, nullptr));
     }
-    SNS_TRY(dev_alloc(&h->partial, (size_t)65536 * 8));
+    // per-block partial sums: vector kernels use <= 2048 blocks x <= 8 sums, the fused SpMV+dot one block per 32 rows
+    SNS_TRY(dev_alloc(&h->partial, std::max<size_t>((size_t)65536 * 8, (size_t)n_nodes / 32 + 64)));
+    SNS_TRY(dev_alloc(&h->partial2, (size_t)4096 * 8));
     SNS_TRY(dev_alloc(&h->d_scal, 256));
     SNS_TRY(dev_alloc(&h->d_sing, 1));
     HIP_TRY(hipMemset(h->d_sing, 0, sizeof(int)));
@@ -1333,7 +1347,7 @@ int sns_destroy(sns_handle h) {
     for (auto p : h->pong) fr(p);
     for (auto p : h->kv) fr(p);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
-    fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
+    fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->partial2); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
     if (h->coarse_graph) (void)hipGraphExecDestroy(h->coarse_graph);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);

@@ -45,6 +45,7 @@ __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
 __global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);
+__global__ void k_reduce_chunks(int nblocks, int nred, const double* partial, double* out);
 __global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);
 __global__ void k_axpby(int64_t n, double a, const double* x, double b, double* y);
 __global__ void k_axpbypcz(int64_t n, double a, const double* x, double b, const double* y, double c, double* z);
@@ -60,10 +61,9 @@ __global__ void k_scale_copy(int64_t n, double a, const double* x, double* y);
 __global__ void k_restrict(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
                            const double* r, double* bc);
 __global__ void k_prolong_add(int32_t n, const int32_t* agg, const uint8_t* free_mask, const double* xc, double* x);
-__global__ void k_galerkin(int64_t nnzb_c, const int64_t* r_ptr, const int32_t* r_idx, const int32_t* slot_row_f,
-                           const int32_t* colind_f, const uint8_t* free_mask, const double* vals_f,
-                           const int32_t* slot_row_c, const int32_t* colind_c, const uint8_t* empty_c,
-                           double* vals_c);
+__global__ void k_galerkin(int64_t nnzb_c, const int64_t* r_ptr, const int32_t* r_idx, const double* vals_f,
+                           const int32_t* slot_row_c, const int32_t* colind_c, const uint8_t* fixed_c,
+                           const int32_t* m_ptr, double* vals_c);
 __global__ void k_empty_coarse(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
                                uint8_t* empty_c);
 __global__ void k_bsr_to_dense(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals,

@@ -1203,6 +1203,23 @@ __global__ __launch_bounds__(256) void k_reduce_final(int nblocks, int nred, con
     if (threadIdx.x == 0) out[k] = red[0];
 }
 
+// first stage of a long reduction: block (c, k) sums partial[b][k] over the 2048 blocks b of chunk c (fixed order)
+__global__ __launch_bounds__(256) void k_reduce_chunks(int nblocks, int nred, const double* __restrict__ partial,
+                                                       double* __restrict__ out) {
+    __shared__ double red[256];
+    const int k = blockIdx.y;
+    const int b0 = blockIdx.x * 2048, b1 = min(nblocks, b0 + 2048);
+    double s = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) s += partial[(int64_t)b * nred + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.x * nred + k] = red[0];
+}
+
 // partial[block] = number of Dirichlet dofs whose current value differs from the prescribed one
 __global__ __launch_bounds__(256) void k_count_bc_violations(int64_t ndof, const uint8_t* __restrict__ bc_mask,
                                                              const double* __restrict__ bc_val,
@@ -1355,33 +1372,51 @@ __global__ __launch_bounds__(256) void k_prolong_add(int32_t n, const int32_t* _
 // coarse dofs with no free fine dof get a unit diagonal.
 __global__ __launch_bounds__(256) void k_galerkin(int64_t nnzb_c, const int64_t* __restrict__ r_ptr,
                                                   const int32_t* __restrict__ r_idx,
-                                                  const int32_t* __restrict__ slot_row_f,
-                                                  const int32_t* __restrict__ colind_f,
-                                                  const uint8_t* __restrict__ free_mask,
                                                   const double* __restrict__ vals_f,
                                                   const int32_t* __restrict__ slot_row_c,
                                                   const int32_t* __restrict__ colind_c,
-                                                  const uint8_t* __restrict__ empty_c,
+                                                  const uint8_t* __restrict__ fixed_c,
+                                                  const int32_t* __restrict__ m_ptr,
                                                   double* __restrict__ vals_c) {
+    // 8 lanes per coarse slot, one double2 each: a fine block is one 128-B line per step, two steps in flight.
+    // Dofs excluded from the transfer (level 0: Dirichlet dofs) need no per-entry test: their rows and columns
+    // of the assembled operator are zero except the unit diagonal (:74), so the only thing to take out again is
+    // one 1.0 per fixed fine dof on the coarse diagonal (fixed_c = number of fixed fine dofs per coarse dof).
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t s = gid >> 4;
-    const int e = (int)(gid & 15);
+    const int64_t s = gid >> 3;
+    const int t = (int)(gid & 7);
     if (s >= nnzb_c) return;
-    const int c = e >> 2, d = e & 3;
-    double v = 0.0;
-    for (int64_t k = r_ptr[s]; k < r_ptr[s + 1]; ++k) {
-        const int32_t fs = r_idx[k];
-        if (free_mask) {
-            const int32_t fr = slot_row_f[fs], fc = colind_f[fs];
-            if (!free_mask[4 * (int64_t)fr + c] || !free_mask[4 * (int64_t)fc + d]) continue;
-        }
-        v += vals_f[(int64_t)fs * 16 + e];
+    double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+    const int64_t k1 = r_ptr[s + 1];
+    int64_t k = r_ptr[s];
+    for (; k + 1 < k1; k += 2) {
+        const int32_t f0 = r_idx[k], f1 = r_idx[k + 1];
+        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)f0 * 16)[t];
+        const double2 b = reinterpret_cast<const double2*>(vals_f + (int64_t)f1 * 16)[t];
+        v0.x += a.x; v0.y += a.y;
+        v1.x += b.x; v1.y += b.y;
     }
-    if (empty_c && slot_row_c[s] == colind_c[s] && c == d && empty_c[4 * (int64_t)slot_row_c[s] + c]) v = 1.0;
-    vals_c[s * 16 + e] = v;
+    if (k < k1) {
+        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)r_idx[k] * 16)[t];
+        v0.x += a.x; v0.y += a.y;
+    }
+    double2 v = make_double2(v0.x + v1.x, v0.y + v1.y);
+    if (fixed_c) {
+        const int32_t I = slot_row_c[s];
+        if (I == colind_c[s]) {
+            const int c = t >> 1;                          // lane t holds entries (c, 2*(t&1)) and (c, 2*(t&1)+1)
+            const int nfix = fixed_c[4 * (int64_t)I + c];
+            const bool all_fixed = nfix == m_ptr[I + 1] - m_ptr[I];     // no free fine dof: unit diagonal
+            if ((t & 1) == (c >> 1)) {
+                if (c & 1) v.y = all_fixed ? 1.0 : v.y - (double)nfix;
+                else v.x = all_fixed ? 1.0 : v.x - (double)nfix;
+            }
+        }
+    }
+    reinterpret_cast<double2*>(vals_c + s * 16)[t] = v;
 }
 
-// empty_c[4I+c] = 1 if aggregate I has no free fine dof of component c
+// fixed_c[4I+c] = number of fine dofs of component c in aggregate I that are excluded from the transfer
 __global__ __launch_bounds__(256) void k_empty_coarse(int32_t nc, const int32_t* __restrict__ m_ptr,
                                                       const int32_t* __restrict__ m_idx,
                                                       const uint8_t* __restrict__ free_mask,
@@ -1390,9 +1425,9 @@ __global__ __launch_bounds__(256) void k_empty_coarse(int32_t nc, const int32_t*
     const int64_t I = gid >> 2;
     const int c = (int)(gid & 3);
     if (I >= nc) return;
-    int any = 0;
-    for (int32_t k = m_ptr[I]; k < m_ptr[I + 1]; ++k) any |= free_mask[4 * (int64_t)m_idx[k] + c];
-    empty_c[4 * I + c] = any ? 0 : 1;
+    int nfix = 0;
+    for (int32_t k = m_ptr[I]; k < m_ptr[I + 1]; ++k) nfix += free_mask[4 * (int64_t)m_idx[k] + c] ? 0 : 1;
+    empty_c[4 * I + c] = (uint8_t)nfix;
 }
 
 // dense N x N (N = 4n) copy of a small BSR matrix
