@@ -21,6 +21,12 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host-side symbolic setup (BSR pattern,
+    # gather lists: OpenMP in libsns.so) wants this rank's share of the cores.  Must happen before libgomp loads.
+    _lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 8) // max(1, _lw))))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

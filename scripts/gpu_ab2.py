@@ -1,0 +1,15 @@
+"""A/B: f32 Jacobi sweep with fewer resident waves per CU (unused dynamic LDS)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
+from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+from stabilized_navier_stokes_flow_fenicsx_amd._lib import check
+m = M.duct_mesh((300, 75, 75), 4.0)
+P = FlowProblem(m, B.duct_bcs(m), reynolds=100.0)
+U, r = P.stokes_solve()
+P.jacobian(U, "ns"); P.pc_setup()
+for kib in (16, 24, 32, 48, 64):
+    ms = (C.c_double * 2)()
+    check(P.lib.sns_bench_variants(P.h, 10 + kib, 4, 10, ms))
+    print(f"dynamic LDS {kib} KiB: base {ms[0]:.4f} ms  limited {ms[1]:.4f} ms  ratio {ms[1] / ms[0]:.3f}", flush=True)

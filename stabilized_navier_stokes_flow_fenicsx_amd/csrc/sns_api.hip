@@ -1705,13 +1705,18 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
     double *x, *y, *b;
     SNS_TRY(get_vec(h, 10, &x)); SNS_TRY(get_vec(h, 11, &y)); SNS_TRY(get_vec(h, 12, &b));
     hipLaunchKernelGGL(k_fill_pattern, dim3(vec_grid(4 * (int64_t)rows)), dim3(256), 0, h->stream, 4 * (int64_t)rows, x);
-    if ((which == 1 || which == 2) && !L.vals32) { set_error("fp32 matrix copy not built (pc_setup with amg_f32_matrix)"); return SNS_E_STATE; }
+    if ((which == 1 || which == 2 || which >= 10) && !L.vals32) { set_error("fp32 matrix copy not built (pc_setup with amg_f32_matrix)"); return SNS_E_STATE; }
     double tot[2] = {0, 0};
     for (int r = 0; r < rounds; ++r)
         for (int v = 0; v < 2; ++v) {
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
             for (int i = 0; i < reps; ++i) {
-                if (which == 3) {                 // fp64 y = Ax: production (nt, cooperative loads) vs the r1e loop
+                if (which >= 10) {                // f32 Jacobi: production vs production with (which-10) KiB of unused
+                                                  // dynamic LDS per workgroup, i.e. fewer resident waves per CU
+                    const int grid = (rows + 63) / 64;
+                    hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0>), dim3(grid), dim3(256), v ? (size_t)(which - 10) * 1024 : 0,
+                                       h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                } else if (which == 3) {          // fp64 y = Ax: production (nt, cooperative loads) vs the r1e loop
                     const int grid = (rows + 31) / 32;
                     if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
                     else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
