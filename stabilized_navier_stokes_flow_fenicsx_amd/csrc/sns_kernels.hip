@@ -1011,56 +1011,42 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = lane & 3;
-    const int32_t row = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
-    const bool live = row < n_rows;
-    double acc0 = 0.0, acc1 = 0.0;
-    // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
-    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
-    const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // The kernel is bound by VMEM issue (cache lines touched per instruction), not by bytes.  Per quad and step of
-    // 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids round) instead of four
-    // broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches component r of each x block).
-    // NT selects experiment variants for the interleaved A/B harness (sns_bench_variants); 0 is production.
-    int32_t k = s;
-    for (; k + 3 < e; k += 4) {
-        int32_t c0, c1, c2, c3;
-        if (NT == 2) {
-            c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
-        } else {
-            const int32_t cme = colind[k + r];
-            c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
-        }
-        const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
-        const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
-        const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
-        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                (double)a0.w * quad_bcast<3>(g0);
-        acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
-                (double)a1.w * quad_bcast<3>(g1);
-        acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
-                (double)a2.w * quad_bcast<3>(g2);
-        acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
-                (double)a3.w * quad_bcast<3>(g3);
-        vp += 16;
-    }
-    if (NT == 1) {
-        if (k < e) {                                 // variant: a row's last 1..3 blocks in one masked step
-            const int rem = e - k;
-            const int32_t cme = colind[k + (r < rem ? r : rem - 1)];
-            const int32_t c0 = quad_bcast_i<0>(cme), c1 = quad_bcast_i<1>(cme), c2 = quad_bcast_i<2>(cme);
-            const float4 a0 = vp[0];
-            const float4 a1 = rem > 1 ? vp[4] : z4;
-            const float4 a2 = rem > 2 ? vp[8] : z4;
-            const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r], g2 = x[4 * (int64_t)c2 + r];
+    // NT = 1 (A/B harness): every wave walks RG consecutive groups of 16 rows instead of one, so waves live RG
+    // times longer and the launch carries RG times fewer workgroups
+    constexpr int RG = (NT == 1) ? 4 : 1;
+#pragma unroll 1
+    for (int rg = 0; rg < RG; ++rg) {
+        const int32_t row = ((blk * 4 + (tid >> 6)) * RG + rg) * 16 + (lane >> 2);
+        const bool live = row < n_rows;
+        double acc0 = 0.0, acc1 = 0.0;
+        // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
+        const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+        const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
+        // Per quad and step of 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids
+        // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
+        // component r of each x block).  NT = 2 keeps the four broadcast index loads for the A/B harness.
+        int32_t k = s;
+        for (; k + 3 < e; k += 4) {
+            int32_t c0, c1, c2, c3;
+            if (NT == 2) {
+                c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
+            } else {
+                const int32_t cme = colind[k + r];
+                c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
+            }
+            const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
+            const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
+            const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
             acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
                     (double)a0.w * quad_bcast<3>(g0);
             acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
                     (double)a1.w * quad_bcast<3>(g1);
             acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
                     (double)a2.w * quad_bcast<3>(g2);
+            acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
+                    (double)a3.w * quad_bcast<3>(g3);
+            vp += 16;
         }
-    } else {
         for (; k < e; ++k) {
             const float4 a0 = vp[0];
             const double g0 = x[4 * (int64_t)colind[k] + r];
@@ -1068,18 +1054,18 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
                     (double)a0.w * quad_bcast<3>(g0);
             vp += 4;
         }
-    }
-    const double acc = acc0 + acc1;                 // (A x)[4*row + r]
-    if (MODE == SPMV_B_MINUS_AX) {
-        if (live) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
-    } else if (MODE == SPMV_JACOBI) {
-        const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
-        const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
-        if (live) {
-            const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
-            const double2 d01 = D2[0], d23 = D2[1];
-            y[4 * (int64_t)row + r] =
-                x[4 * (int64_t)row + r] + omega * (d01.x * r0 + d01.y * r1 + d23.x * r2 + d23.y * r3);
+        const double acc = acc0 + acc1;                 // (A x)[4*row + r]
+        if (MODE == SPMV_B_MINUS_AX) {
+            if (live) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
+        } else if (MODE == SPMV_JACOBI) {
+            const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
+            const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
+            if (live) {
+                const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
+                const double2 d01 = D2[0], d23 = D2[1];
+                y[4 * (int64_t)row + r] =
+                    x[4 * (int64_t)row + r] + omega * (d01.x * r0 + d01.y * r1 + d23.x * r2 + d23.y * r3);
+            }
         }
     }
 }
