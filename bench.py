@@ -274,6 +274,10 @@ def main():
                                f"{args.ksp} rtol 1e-8, bt line search)",
                    "parallelism": (f"x-slab element partition x{world}, {n_tets_global // world} tets per GPU"
                                    if world > 1 else "single GPU"),
+                   "scaling_note": ("weak: every GPU keeps BASELINE config 5's 10.1 M-tet share (duct refined by "
+                                    "N^(1/3)); --strong splits the one 10.1 M-tet mesh N ways (DESIGN.md section 7)"
+                                    if weak else ("strong: the one mesh split N ways" if world > 1 else
+                                                  "N=1 is BASELINE config 5's mesh on one GPU")),
                    "newton_log_fnorm_kspits_reason": [(float(f"{a:.3e}"), b, c) for a, b, c in log],
                    "phase_ms_per_step": {"assemble": round(tm.assemble_ms / args.steps, 3),
                                          "pc_setup": round(tm.pc_setup_ms / args.steps, 3),
