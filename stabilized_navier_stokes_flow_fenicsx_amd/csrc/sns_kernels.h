@@ -38,7 +38,7 @@ template <int MODE, int FINE, int NT>
 __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial);
-template <int MODE, int FINE, int NT>
+template <int MODE, int FINE, int VAR>
 __global__ void k_spmv_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const float* vals,
                            const double* x, double* y, const double* bvec, const double* dinv, double omega);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);

@@ -1001,7 +1001,8 @@ __device__ __forceinline__ double quad_bcast(double v) { return quad_perm<J * 0x
 template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true); }
 
-template <int MODE, int FINE, int NT>
+// VAR: 0 = production; 1, 2 = variants kept for the interleaved A/B harness (sns_bench_variants)
+template <int MODE, int FINE, int VAR>
 __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colind,
                                                   const float* __restrict__ vals, const double* __restrict__ x,
@@ -1011,9 +1012,9 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = lane & 3;
-    // NT = 1 (A/B harness): every wave walks RG consecutive groups of 16 rows instead of one, so waves live RG
+    // VAR = 1 (A/B harness): every wave walks RG consecutive groups of 16 rows instead of one, so waves live RG
     // times longer and the launch carries RG times fewer workgroups
-    constexpr int RG = (NT == 1) ? 4 : 1;
+    constexpr int RG = (VAR == 1) ? 4 : 1;
 #pragma unroll 1
     for (int rg = 0; rg < RG; ++rg) {
         const int32_t row = ((blk * 4 + (tid >> 6)) * RG + rg) * 16 + (lane >> 2);
@@ -1024,11 +1025,11 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
         const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
         // Per quad and step of 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids
         // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
-        // component r of each x block).  NT = 2 keeps the four broadcast index loads for the A/B harness.
+        // component r of each x block).  VAR = 2 keeps the four broadcast index loads for the A/B harness.
         int32_t k = s;
         for (; k + 3 < e; k += 4) {
             int32_t c0, c1, c2, c3;
-            if (NT == 2) {
+            if (VAR == 2) {
                 c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
             } else {
                 const int32_t cme = colind[k + r];
