@@ -96,6 +96,10 @@ typedef struct {
                                coarse sweeps are cheap and plain aggregation needs them */
     int    amg_nu_deep;     /* sweeps on levels >= 3 (2; 0 = same as amg_nu_coarse): these levels are launch-bound */
     int    amg_nu_l2;       /* sweeps on level 2 (6; 0 = same as amg_nu_coarse) */
+    int    amg_sweep_exchange_rows; /* multi-GPU: AMG levels with at most this many rows per rank exchange the ghost
+                               iterate before EVERY smoother sweep (exact global block-Jacobi) instead of smoothing
+                               rank-locally; 0 (default) = never.  Fewer iterations, 2*nu instead of 1 exchange per
+                               level and cycle */
     int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
                                state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
 } sns_options;

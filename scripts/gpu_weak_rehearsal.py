@@ -7,6 +7,7 @@ import numpy as np, torch
 from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem, Team
 base = (300, 75, 75) if len(sys.argv) < 3 else tuple(int(c) for c in sys.argv[2].split(","))
+extra = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 else [])}
 for N in [int(a) for a in sys.argv[1].split(",")]:
     sc = float(N) ** (1.0 / 3.0)
     cells = tuple(int(round(c * sc)) for c in base)
@@ -16,7 +17,7 @@ for N in [int(a) for a in sys.argv[1].split(",")]:
         t0 = time.time()
         part = PT.duct_slab_part(cells, 4.0, rank, N)
         t1 = time.time()
-        P = FlowProblem.from_part(part, group=team, reynolds=200.0, snes_max_it=1)
+        P = FlowProblem.from_part(part, group=team, reynolds=200.0, snes_max_it=1, **extra)
         U, r = P.stokes_solve()
         w, n1 = P.newton_solve(U.clone())
         w, n2 = P.newton_solve(w)

@@ -762,12 +762,19 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
+    // distributed: on levels with few rows per rank the sweeps see the neighbours' current iterate (one small
+    // exchange per sweep); on the big levels they stay rank-local (ghost values zero) and only the residual is exact
+    const bool sx = L.xg && rows <= h->opt.amg_sweep_exchange_rows;
     if (rows > 0) hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
     for (int s = 1; s < nu; ++s) {
+        if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
-    if (L.xg) {      // distributed: true residual needs the neighbours' iterate; smoothing itself stays rank-local
+    if (sx) {
+        SNS_TRY(exchange_level(h, l, cur));
+        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
+    } else if (L.xg) {      // true residual needs the neighbours' iterate
         HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         SNS_TRY(exchange_level(h, l, L.xg));
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
@@ -781,6 +788,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     for (int s = 0; s < nu; ++s) {
+        if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
@@ -1202,6 +1210,7 @@ void sns_default_options(sns_options* o) {
     o->amg_nu_deep = 2;
     o->amg_nu_l2 = 6;
     o->assembly_fused = 1;
+    o->amg_sweep_exchange_rows = 0;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1373,7 +1382,18 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     if (!h || !o) return SNS_E_ARG;
     const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix);
     const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
+    const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows);
     h->opt = *o;
+    if (sweep_exchange_changed) {
+        // rank-local sweeps rely on ghost tails that are never written (zero); sweeps with exchanges fill them
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t l = 0; l < h->levels.size(); ++l) {
+            Level& L = h->levels[l];
+            const size_t nb = 4 * (size_t)L.n * sizeof(double);
+            if (L.x) HIP_TRY(hipMemset(L.x, 0, nb));
+            if (l < h->pong.size() && h->pong[l]) HIP_TRY(hipMemset(h->pong[l], 0, nb));
+        }
+    }
     if (pc_changed || damping_changed) h->pc_ready = false;
     if (damping_changed)
         for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }   // re-estimate and re-verify

@@ -412,6 +412,13 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
         if kind == "slab":
             P = gpu.from_part(PT.duct_slab_part((36, 8, 8), 4.0, rank, nranks), group=team, reynolds=Re)
             part = P.part
+            # exact global block-Jacobi smoothing (ghost exchange before every sweep on every level): same fields,
+            # no more Krylov iterations than with rank-local sweeps
+            P.set_options(amg_sweep_exchange_rows=1 << 30)
+            Ux, rx = P.stokes_solve()
+            P.set_options(amg_sweep_exchange_rows=0)
+            U0, r0 = P.stokes_solve()
+            assert rx.reason > 0 and rx.its <= r0.its and float((Ux - U0).norm() / U0.norm()) < 1e-4
         else:
             part = PT.build_local_part(m, mask, g, owner, rank, nranks)
             P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
