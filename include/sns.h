@@ -100,6 +100,9 @@ typedef struct {
                                iterate before EVERY smoother sweep (exact global block-Jacobi) instead of smoothing
                                rank-locally; 0 (default) = never.  Fewer iterations, 2*nu instead of 1 exchange per
                                level and cycle */
+    int    amg_replicate_rows; /* multi-GPU: the first AMG level (>= 1) with at most this many GLOBAL rows, and all below,
+                               are held and cycled redundantly by every rank (values all-gathered at setup, one
+                               all-gather of the right-hand side per cycle, no exchanges below); 0 = off.  Default 65536 */
     int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
                                state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
 } sns_options;

@@ -116,6 +116,15 @@ struct sns_ctx {
     int cg_maxn = 0;                              // padded owned coarsest nodes per rank
     int cg_N = 0;                                 // 4 * nranks * cg_maxn (0 = not used)
     std::vector<int> cg_counts;                   // owned coarsest nodes of every rank
+    // multi-GPU: replicated tail of the hierarchy.  levels[rep_level] is a copy of the GLOBAL operator of level
+    // rep_level-1 held by every rank (all-gathered values); it and everything below is cycled redundantly on every
+    // rank without any exchange.  0 = none.
+    int rep_level = 0;
+    int32_t rep_maxn = 0, rep_NG = 0, rep_off = 0;
+    int64_t rep_maxnz = 0;
+    int32_t* rep_valmap = nullptr;                // [nranks*maxnz] gathered slot -> slot of the replicated level (-1: padding)
+    int32_t* rep_rowmap = nullptr;                // [NG] row of the replicated level -> gathered row (rank*maxn + i)
+    double *rep_vsend = nullptr, *rep_vrecv = nullptr, *rep_bsend = nullptr, *rep_brecv = nullptr;
     int32_t* cg_colmap = nullptr;                 // local coarsest node -> global (padded) node id
     double *cg_rows = nullptr, *cg_full = nullptr, *cg_send = nullptr, *cg_recv = nullptr;
     std::vector<std::vector<int32_t>> ghost_gid;  // per level: (owner rank, owner-local id) of each ghost node
@@ -290,6 +299,169 @@ int global_sum(sns_ctx* h, double* v, int count) {
     return SNS_OK;
 }
 
+// host-side all-gather of `mine` (same length on every rank) through the communicator
+int host_allgather(sns_ctx* h, const std::vector<double>& mine, std::vector<double>& all) {
+    Comm* c = h->comm.get();
+    const size_t len = mine.size();
+    double *ds = nullptr, *dr = nullptr;
+    SNS_TRY(dev_alloc(&ds, std::max<size_t>(1, len)));
+    SNS_TRY(dev_alloc(&dr, std::max<size_t>(1, len * c->nranks)));
+    HIP_TRY(hipMemcpy(ds, mine.data(), len * sizeof(double), hipMemcpyHostToDevice));
+    SNS_TRY(comm_allgather(c, ds, dr, (int)len, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    all.resize(len * c->nranks);
+    HIP_TRY(hipMemcpy(all.data(), dr, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(ds);
+    (void)hipFree(dr);
+    return SNS_OK;
+}
+
+int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg) {
+    h->levels.emplace_back();
+    h->slot_row.push_back(nullptr);
+    h->empty_c.push_back(nullptr);
+    h->pong.push_back(nullptr);
+    Level& C = h->levels.back();
+    SNS_TRY(upload_pattern(C, P, &h->slot_row.back(), h->stream));
+    C.n_owned = n_owned;
+    SNS_TRY(alloc_level_vectors(C));
+    SNS_TRY(dev_alloc(&h->pong.back(), 4 * (size_t)std::max(1, C.n)));
+    HIP_TRY(hipMemset(h->pong.back(), 0, 4 * (size_t)std::max(1, C.n) * sizeof(double)));
+    if (with_xg) {
+        SNS_TRY(dev_alloc(&C.xg, 4 * (size_t)std::max(1, C.n)));
+        HIP_TRY(hipMemset(C.xg, 0, 4 * (size_t)std::max(1, C.n) * sizeof(double)));
+    }
+    return SNS_OK;
+}
+
+// Multi-GPU: from level R on, every rank holds the GLOBAL operator (values all-gathered at every numeric setup)
+// and cycles the rest of the hierarchy redundantly: no exchanges below R, and the smoothing there is the exact
+// global block-Jacobi instead of a rank-local one (thin partitions lose their convergence on the deep levels
+// otherwise).  `cur` is the local pattern of level R (owned rows, local column ids), collective over the ranks.
+int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_owned) {
+    const sns_options& o = h->opt;
+    Comm* c = h->comm.get();
+    const int nr = c->nranks, me = c->rank;
+    std::vector<double> cnt((size_t)2 * nr, 0.0);
+    cnt[me] = (double)n_owned;
+    cnt[nr + me] = (double)cur.rowptr[n_owned];
+    SNS_TRY(global_sum(h, cnt.data(), 2 * nr));
+    std::vector<int64_t> off((size_t)nr + 1, 0);
+    int32_t maxn = 1;
+    int64_t maxnz = 1;
+    for (int r = 0; r < nr; ++r) {
+        off[r + 1] = off[r] + (int64_t)cnt[r];
+        maxn = std::max(maxn, (int32_t)cnt[r]);
+        maxnz = std::max(maxnz, (int64_t)cnt[nr + r]);
+    }
+    const int32_t NG = (int32_t)off[nr];
+    const std::vector<int32_t>& g_own = h->ghost_own[R];
+    const std::vector<int32_t>& g_gid = h->ghost_gid[R];
+    // [0, maxn): row lengths; [maxn, maxn + maxnz): global column ids of my slots
+    std::vector<double> mine((size_t)maxn + (size_t)maxnz, -1.0), all;
+    for (int32_t i = 0; i < maxn; ++i) mine[i] = i < n_owned ? (double)(cur.rowptr[i + 1] - cur.rowptr[i]) : 0.0;
+    for (int32_t sidx = 0; sidx < cur.rowptr[n_owned]; ++sidx) {
+        const int32_t j = cur.colind[sidx];
+        int64_t gj;
+        if (j < n_owned) gj = off[me] + j;
+        else {
+            const size_t q = (size_t)(j - n_owned);
+            if (q >= g_own.size()) { set_error("replicated tail: ghost column without an owner record"); return SNS_E_STATE; }
+            gj = off[g_own[q]] + g_gid[q];
+        }
+        mine[(size_t)maxn + sidx] = (double)gj;
+    }
+    SNS_TRY(host_allgather(h, mine, all));
+    HostPattern G;
+    G.n = NG;
+    G.rowptr.assign((size_t)NG + 1, 0);
+    std::vector<int32_t> valmap((size_t)nr * maxnz, -1), rowmap((size_t)std::max(1, NG), 0);
+    const size_t LEN = mine.size();
+    for (int r = 0; r < nr; ++r)
+        for (int32_t i = 0; i < (int32_t)cnt[r]; ++i) {
+            G.rowptr[(size_t)off[r] + i + 1] = (int32_t)all[r * LEN + i];
+            rowmap[(size_t)off[r] + i] = r * maxn + i;
+        }
+    for (int32_t g = 0; g < NG; ++g) G.rowptr[g + 1] += G.rowptr[g];
+    G.nnzb = G.rowptr[NG];
+    G.colind.resize((size_t)G.nnzb);
+    G.diag.assign((size_t)NG, 0);
+    std::vector<std::pair<int32_t, int32_t>> ent;
+    for (int r = 0; r < nr; ++r) {
+        int64_t src = 0;
+        for (int32_t i = 0; i < (int32_t)cnt[r]; ++i) {
+            const int32_t g = (int32_t)off[r] + i;
+            const int32_t len = (int32_t)all[r * LEN + i];
+            ent.clear();
+            for (int32_t k = 0; k < len; ++k, ++src)
+                ent.emplace_back((int32_t)all[r * LEN + maxn + src], (int32_t)(r * maxnz + src));
+            std::sort(ent.begin(), ent.end());
+            bool has_diag = false;
+            for (int32_t k = 0; k < len; ++k) {
+                const int32_t slot = G.rowptr[g] + k;
+                if (ent[k].first < 0 || ent[k].first >= NG || (k > 0 && ent[k].first == ent[k - 1].first)) {
+                    set_error("replicated tail: inconsistent global pattern");
+                    return SNS_E_STATE;
+                }
+                G.colind[slot] = ent[k].first;
+                valmap[ent[k].second] = slot;
+                if (ent[k].first == g) { G.diag[g] = slot; has_diag = true; }
+            }
+            if (!has_diag) { set_error("replicated tail: row without a diagonal block"); return SNS_E_STATE; }
+        }
+    }
+    h->rep_level = (int)h->levels.size();
+    h->rep_maxn = maxn;
+    h->rep_maxnz = maxnz;
+    h->rep_NG = NG;
+    h->rep_off = (int32_t)off[me];
+    SNS_TRY(append_level(h, G, NG, false));
+    h->ghost_own.emplace_back();
+    h->ghost_gid.emplace_back();
+    SNS_TRY(dev_upload(&h->rep_valmap, valmap, h->stream));
+    SNS_TRY(dev_upload(&h->rep_rowmap, rowmap, h->stream));
+    SNS_TRY(dev_alloc(&h->rep_vsend, (size_t)maxnz * 16));
+    SNS_TRY(dev_alloc(&h->rep_vrecv, (size_t)maxnz * 16 * nr));
+    SNS_TRY(dev_alloc(&h->rep_bsend, (size_t)maxn * 4));
+    SNS_TRY(dev_alloc(&h->rep_brecv, (size_t)maxn * 4 * nr));
+    HIP_TRY(hipMemset(h->rep_vsend, 0, (size_t)maxnz * 16 * sizeof(double)));
+    HIP_TRY(hipMemset(h->rep_bsend, 0, (size_t)maxn * 4 * sizeof(double)));
+    // plain serial aggregation below (identical on every rank: same input, deterministic code)
+    HostPattern curp = std::move(G);
+    int32_t n_own = NG;
+    for (int l = h->rep_level; (int)h->levels.size() < o.amg_max_levels + 1; ++l) {
+        if (n_own <= o.amg_coarse_size) break;
+        std::vector<int32_t> agg;
+        int32_t nc = 0;
+        aggregate_nodes(curp, n_own, std::min(255, std::max(2, o.amg_agg_size)), agg, nc);
+        if (nc >= n_own || nc == 0) break;
+        HostAggregation A;
+        build_coarse_from_agg(curp, n_own, agg, nc, nc, A);
+        {
+            Level& L = h->levels[l];
+            L.nc = nc;
+            SNS_TRY(dev_upload(&L.agg, A.agg, h->stream));
+            SNS_TRY(dev_upload(&L.m_ptr, A.m_ptr, h->stream));
+            SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
+            SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
+            SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+        }
+        SNS_TRY(append_level(h, A.coarse, nc, false));
+        h->ghost_own.emplace_back();
+        h->ghost_gid.emplace_back();
+        curp = std::move(A.coarse);
+        n_own = nc;
+    }
+    Level& last = h->levels.back();
+    if (last.n <= std::max(o.amg_coarse_size, 40)) {
+        const size_t N = 4 * (size_t)last.n;
+        SNS_TRY(dev_alloc(&last.dense_inv, N * N));
+        SNS_TRY(dev_alloc(&h->d_piv, N));
+    }
+    h->tm.amg_levels = (int)h->levels.size() - 1;
+    return SNS_OK;
+}
+
 // Build the aggregation hierarchy (symbolic, once per mesh; collective over the ranks).
 // Aggregates never cross ranks, but the Galerkin operators keep every cross-rank coupling:
 // a ghost fine node's aggregate becomes a ghost coarse node, and each level gets its own
@@ -315,6 +487,15 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         HIP_TRY(hipMemset(h->levels[0].xg, 0, 4 * (size_t)h->levels[0].n * sizeof(double)));
     }
     for (int l = 0; l + 1 < o.amg_max_levels; ++l) {
+        if (dist && l >= 1 && o.amg_replicate_rows > 0) {
+            double g[1] = {(double)n_owned};
+            SNS_TRY(global_sum(h, g, 1));
+            // the replicated level must fit the scratch vectors sized by the local fine level
+            double fits[1] = {g[0] <= (double)h->n_owned ? 0.0 : 1.0};
+            SNS_TRY(global_sum(h, fits, 1));
+            if (g[0] <= (double)o.amg_replicate_rows && g[0] > (double)std::max(o.amg_coarse_size, 40) && fits[0] == 0.0)
+                return build_replicated_tail(h, l, cur, n_owned);
+        }
         double flag[1] = {n_owned > per_rank_coarse ? 1.0 : 0.0};
         SNS_TRY(global_sum(h, flag, 1));
         if (flag[0] == 0.0) break;
@@ -599,6 +780,18 @@ int pc_setup(sns_ctx* h) {
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
         const int32_t rows = L.n_owned;
+        if (h->rep_level > 0 && l == h->rep_level - 1) {
+            // level R is only the source of the replicated copy: all-gather my rows' blocks, scatter them into place
+            Level& C = h->levels[h->rep_level];
+            if (L.nnzb > 0)
+                HIP_TRY(hipMemcpyAsync(h->rep_vsend, L.vals, (size_t)L.nnzb * 16 * sizeof(double), hipMemcpyDeviceToDevice,
+                                       h->stream));
+            SNS_TRY(comm_allgather(h->comm.get(), h->rep_vsend, h->rep_vrecv, (int)(h->rep_maxnz * 16), h->stream));
+            const int64_t nsrc = h->rep_maxnz * h->comm->nranks;
+            hipLaunchKernelGGL(k_scatter_blocks, dim3((unsigned)((nsrc * 8 + 255) / 256)), dim3(256), 0, h->stream, nsrc,
+                               h->rep_valmap, h->rep_vrecv, C.vals);
+            continue;
+        }
         if (rows > 0)
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
@@ -679,13 +872,15 @@ constexpr int GRAPH_LEVEL = 2;     // levels >= 2 of a 10 M-tet hierarchy are ~7
 // inside the cycle is a host-driven RCCL group).  Any capture failure disables the graph for good.
 int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     const bool dist = h->comm && h->comm->active() && h->comm->nranks > 1;
-    if (l != GRAPH_LEVEL || dist || h->graph_disabled || (int)h->levels.size() <= GRAPH_LEVEL + 1)
-        return vcycle(h, l, b, x);
+    // distributed runs: only the replicated tail is free of exchanges and can be captured
+    const int gl = dist ? h->rep_level : GRAPH_LEVEL;
+    if (gl <= 0 || l != gl || h->graph_disabled || (int)h->levels.size() <= gl + 1) return vcycle(h, l, b, x);
     std::vector<double> sig;
     for (auto& L : h->levels) sig.push_back(L.omega);
     sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_nu_deep);
     sig.push_back(h->opt.amg_nu_l2);
     sig.push_back(h->opt.amg_f32_matrix);
+    sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
         if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
         if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -723,6 +918,20 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     const bool last = (l + 1 == (int)h->levels.size());
     const double om = L.omega;
     const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
+    if (h->rep_level > 0 && l == h->rep_level - 1) {
+        // all-gather the right-hand side, cycle the replicated tail, keep my rows of the result
+        Level& C = h->levels[h->rep_level];
+        if (rows > 0)
+            HIP_TRY(hipMemcpyAsync(h->rep_bsend, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        SNS_TRY(comm_allgather(h->comm.get(), h->rep_bsend, h->rep_brecv, 4 * h->rep_maxn, h->stream));
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((4 * (int64_t)h->rep_NG + 255) / 256)), dim3(256), 0, h->stream,
+                           h->rep_NG, h->rep_rowmap, h->rep_brecv, C.b);
+        SNS_TRY(coarse_cycle(h, h->rep_level, C.b, C.x));
+        if (rows > 0)
+            HIP_TRY(hipMemcpyAsync(x, C.x + 4 * (size_t)h->rep_off, 4 * (size_t)rows * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        return SNS_OK;
+    }
     if (last) {
         if (h->cg_N > 0) {
             const int N = h->cg_N, mr = 4 * h->cg_maxn;
@@ -755,10 +964,11 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     // sweeps per level: the fine level is the expensive one (1 sweep); level 1 and 2 are cheap and are where
     // plain aggregation needs the smoothing (4 and 6); levels >= 3 are launch-bound (2).  Measured on the
     // 10 M-tet Jacobian: (1,4,6,2) 40-42 its / 180-186 ms; (1,4,4,4) 45 / 204; (2,2,2,2) 54 / 323.
+    const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
     int nu = std::max(1, h->opt.amg_nu);
-    if (l >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;
-    else if (l == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2;
-    else if (l >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;
+    if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;
+    else if (ll == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2;
+    else if (ll >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
@@ -1211,6 +1421,7 @@ void sns_default_options(sns_options* o) {
     o->amg_nu_l2 = 6;
     o->assembly_fused = 1;
     o->amg_sweep_exchange_rows = 0;
+    o->amg_replicate_rows = 65536;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1356,7 +1567,8 @@ int sns_destroy(sns_handle h) {
     for (auto p : h->pong) fr(p);
     for (auto p : h->kv) fr(p);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
-    fr(h->d_piv); fr(h->d_sing); fr(h->partial); fr(h->partial2); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
+    fr(h->d_piv); fr(h->d_sing); fr(h->rep_valmap); fr(h->rep_rowmap); fr(h->rep_vsend); fr(h->rep_vrecv); fr(h->rep_bsend); fr(h->rep_brecv);
+    fr(h->partial); fr(h->partial2); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
     if (h->coarse_graph) (void)hipGraphExecDestroy(h->coarse_graph);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1680,7 +1892,7 @@ int sns_export(sns_handle h, int what, void* dst, int64_t nbytes) {
 int sns_get_timings(sns_handle h, sns_timings* t) {
     if (!h || !t) return SNS_E_ARG;
     *t = h->tm;
-    t->amg_levels = (int)h->levels.size();
+    t->amg_levels = (int)h->levels.size() - (h->rep_level > 0 ? 1 : 0);
     return SNS_OK;
 }
 int sns_reset_timings(sns_handle h) {

@@ -64,6 +64,8 @@ __global__ void k_prolong_add(int32_t n, const int32_t* agg, const uint8_t* free
 __global__ void k_galerkin(int64_t nnzb_c, const int64_t* r_ptr, const int32_t* r_idx, const double* vals_f,
                            const int32_t* slot_row_c, const int32_t* colind_c, const uint8_t* fixed_c,
                            const int32_t* m_ptr, double* vals_c);
+__global__ void k_scatter_blocks(int64_t nsrc, const int32_t* valmap, const double* src, double* dst);
+__global__ void k_gather_rows(int32_t n, const int32_t* rowmap, const double* src, double* dst);
 __global__ void k_empty_coarse(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
                                uint8_t* empty_c);
 __global__ void k_bsr_to_dense(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals,

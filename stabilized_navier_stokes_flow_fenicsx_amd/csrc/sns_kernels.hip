@@ -1354,6 +1354,28 @@ __global__ __launch_bounds__(256) void k_prolong_add(int32_t n, const int32_t* _
     x[4 * i + c] += xc[4 * (int64_t)I + c];
 }
 
+// dst block valmap[s] <- src block s (multi-GPU: all-gathered rows of a level scattered into the replicated copy)
+__global__ __launch_bounds__(256) void k_scatter_blocks(int64_t nsrc, const int32_t* __restrict__ valmap,
+                                                        const double* __restrict__ src, double* __restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 3;
+    const int t = (int)(gid & 7);
+    if (s >= nsrc) return;
+    const int32_t d = valmap[s];
+    if (d < 0) return;
+    reinterpret_cast<double2*>(dst + (int64_t)d * 16)[t] = reinterpret_cast<const double2*>(src + s * 16)[t];
+}
+
+// dst row g <- src row rowmap[g] (4 doubles per row)
+__global__ __launch_bounds__(256) void k_gather_rows(int32_t n, const int32_t* __restrict__ rowmap,
+                                                     const double* __restrict__ src, double* __restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (g >= n) return;
+    dst[4 * g + c] = src[4 * (int64_t)rowmap[g] + c];
+}
+
 // Galerkin coarse operator A_c = P0^T A P0 as a gather: coarse slot <- sum of fine
 // slots; entries whose fine row/col dof is excluded from the transfer are skipped;
 // coarse dofs with no free fine dof get a unit diagonal.

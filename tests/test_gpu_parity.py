@@ -383,14 +383,18 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     assert nres.reason > 0 and msh.num_tets == 6 ** 4
 
 
-@pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab")])
+@pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab"), (4, "duct-rep"),
+                                         (5, "cavity-rep")])
 def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
     exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
     GPU over the in-process team transport; RCCL only replaces the transport on a multi-GPU node."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
     from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
-    if kind == "duct":
+    # "-rep": a small coarsest size forces a REPLICATED tail of the hierarchy from level 1 on (every rank holds the
+    # global level-1 operator, all-gathered values, and cycles the levels below redundantly without exchanges)
+    kw = dict(amg_coarse_size=24, amg_replicate_rows=1 << 20) if kind.endswith("-rep") else {}
+    if kind.startswith("duct"):
         m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
         mask, g = B.duct_bcs(m).flatten()
     elif kind == "slab":                            # bench.py's weak-scaling layout: thin x-slabs, each rank meshes its own
@@ -400,7 +404,7 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
         m = M.cavity_mesh(12, jitter=0.1)
         mask, g = B.cavity_bcs(m).flatten()
     Re = 12.0
-    Ps = gpu(m, (mask, g), reynolds=Re)
+    Ps = gpu(m, (mask, g), reynolds=Re, **kw)
     Us, rs = Ps.stokes_solve()
     ws, ns = Ps.newton_solve(Us.clone())
     Us, ws = Us.cpu().numpy(), ws.cpu().numpy()
@@ -421,23 +425,25 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
             assert rx.reason > 0 and rx.its <= r0.its and float((Ux - U0).norm() / U0.norm()) < 1e-4
         else:
             part = PT.build_local_part(m, mask, g, owner, rank, nranks)
-            P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
+            P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team, **kw)
         U, r = P.stokes_solve()
         w, n = P.newton_solve(U.clone())
-        out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n)
+        out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n, P.timings().amg_levels)
         P.close()
         return out
 
     outs = team.run(work)
     team.close()
     Ug, wg = np.zeros(m.num_dofs), np.zeros(m.num_dofs)
-    for part, U, r, w, n in outs:
+    for part, U, r, w, n, nlev in outs:
         gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
         Ug[gd], wg[gd] = U[:4 * part.n_owned], w[:4 * part.n_owned]
         assert r.reason > 0 and n.reason == ns.reason and n.its == ns.its
         assert (r.its, n.ksp_its) == (outs[0][2].its, outs[0][4].ksp_its)      # every rank took the same decisions
     assert rel(Ug, Us) < 1e-6 and rel(wg, ws) < 1e-8
     assert outs[0][2].its <= 2 * rs.its + 4                                   # coarse correction stays global
+    if kw:
+        assert outs[0][5] >= 3                                                # fine, distributed level 1, replicated tail
 
 
 @pytest.mark.parametrize("kind,Re,n", [("cavity", 100.0, 12), ("channel", 30.0, 8)])
