@@ -103,6 +103,8 @@ typedef struct {
     int    amg_replicate_rows; /* multi-GPU: the first AMG level (>= 1) with at most this many GLOBAL rows, and all below,
                                are held and cycled redundantly by every rank (values all-gathered at setup, one
                                all-gather of the right-hand side per cycle, no exchanges below); 0 = off.  Default 65536 */
+    int    amg_post_exchange; /* multi-GPU: 1 (default) = one more ghost exchange per level and cycle, after the coarse-grid
+                               correction, so that the post-smoothing sweeps see the neighbours' corrected iterate */
     int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
                                state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
 } sns_options;

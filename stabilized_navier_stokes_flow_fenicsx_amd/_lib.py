@@ -30,7 +30,7 @@ class SnsOptions(C.Structure):
         ("gmres_restart", C.c_int), ("snes_rtol", C.c_double), ("snes_atol", C.c_double),
         ("snes_stol", C.c_double), ("snes_max_it", C.c_int), ("amg_max_levels", C.c_int),
         ("amg_coarse_size", C.c_int), ("amg_agg_size", C.c_int), ("amg_nu", C.c_int),
-        ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int), ("amg_f32_matrix", C.c_int), ("amg_nu_coarse", C.c_int), ("amg_nu_deep", C.c_int), ("amg_nu_l2", C.c_int), ("amg_sweep_exchange_rows", C.c_int), ("amg_replicate_rows", C.c_int), ("assembly_fused", C.c_int),
+        ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int), ("amg_f32_matrix", C.c_int), ("amg_nu_coarse", C.c_int), ("amg_nu_deep", C.c_int), ("amg_nu_l2", C.c_int), ("amg_sweep_exchange_rows", C.c_int), ("amg_replicate_rows", C.c_int), ("amg_post_exchange", C.c_int), ("assembly_fused", C.c_int),
     ]
 
 

@@ -709,6 +709,25 @@ int get_vec(sns_ctx* h, size_t k, double** out);
 // operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at the smoothing-optimal 4/(3 |lambda|max).  (Measured cliff on the coarse
 // levels of the 10 M-tet Jacobian: w = 0.80 converges in 45 iterations, w >= 0.82 overflows, although the
 // dominant mode itself is still damped there -- the offending mode is not the one of largest modulus.)
+inline bool level_sx(const sns_ctx* h, const Level& L) { return L.xg && L.n_owned <= h->opt.amg_sweep_exchange_rows; }
+// sweeps per level: the fine level is the expensive one (1 sweep); level 1 and 2 are cheap and are where
+// plain aggregation needs the smoothing (4 and 6); levels >= 3 are launch-bound (2).  Measured on the
+// 10 M-tet Jacobian: (1,4,6,2) 40-42 its / 180-186 ms; (1,4,4,4) 45 / 204; (2,2,2,2) 54 / 323.
+inline int level_nu(const sns_ctx* h, int l) {
+    const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
+    int nu = std::max(1, h->opt.amg_nu);
+    if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;
+    else if (ll == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2;
+    else if (ll >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;
+    return nu;
+}
+// one exchange after the coarse-grid correction makes a SINGLE post-smoothing sweep the exact global block-Jacobi
+// sweep; with several sweeps the ghost values would be frozen while the owned ones move, which measurably hurts
+// the Stokes operator (8 slabs of the 10 M-tet duct: 47 -> 65 iterations) -- so only where nu = 1 (the fine level)
+inline bool level_px(const sns_ctx* h, int l, const Level& L) {
+    return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1;
+}
+inline bool uses_ghosts_in_sweeps(const sns_ctx* h, int l, const Level& L) { return level_sx(h, L) || level_px(h, l, L); }
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     Level& L = h->levels[l];
     const int32_t rows = L.n_owned;
@@ -719,16 +738,24 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     double* z = L.x;
     // deterministic start vector with all frequencies: x_i = 1 + (i*2654435761 mod 1024)/1024 via axpby on an iota is
     // overkill; use b of the last solve if any, else the diagonal-inverse row sums: simplest robust choice = all ones
-    hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, x);
+    if (rows > 0) hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, x);
     double lam = 0.0;
     const int iters = 12;
+    // distributed levels whose sweeps see exchanged ghost values are damped for the GLOBAL operator; purely
+    // rank-local sweeps (ghost values zero) for the rank-local one
+    const bool glob = uses_ghosts_in_sweeps(h, l, L);
     for (int it = 0; it < iters; ++it) {
+        if (glob) SNS_TRY(exchange_level(h, l, x));
         launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
-        hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
-        hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, z, h->partial);   // (x.z, z.z)
-        reduce_local(h, g, 2, h->d_scal + 16 + 2 * it);
+        if (rows > 0) {
+            hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, z, h->partial);   // (x.z, z.z)
+        }
+        if (glob) SNS_TRY(reduce_to(h, g, 2, h->d_scal + 16 + 2 * it));
+        else reduce_local(h, g, 2, h->d_scal + 16 + 2 * it);
         // normalise with the device-side norm: x = z / ||z||  (scale read on device)
-        hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, h->d_scal + 16 + 2 * it + 1, z, x);
+        if (rows > 0)
+            hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, h->d_scal + 16 + 2 * it + 1, z, x);
     }
     std::vector<double> v(2 * iters);
     SNS_TRY(fetch(h, h->d_scal + 16, 2 * iters, v.data()));
@@ -752,17 +779,21 @@ int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
     double* xb = L.r;
     double* zero = nullptr;
     SNS_TRY(get_vec(h, 13, &zero));                      // level sizes never exceed the fine level
-    HIP_TRY(hipMemsetAsync(zero, 0, nd * sizeof(double), h->stream));
+    if (nd > 0) HIP_TRY(hipMemsetAsync(zero, 0, nd * sizeof(double), h->stream));
     // keep x0 intact (it seeds later trials): first sweep x0 -> xa, then ping-pong xa <-> xb
+    const bool glob = uses_ghosts_in_sweeps(h, l, L);
+    if (glob) SNS_TRY(exchange_level(h, l, x0));
     launch_spmv<SPMV_JACOBI>(h, L, rows, x0, xa, zero, omega, nullptr);
     double* cur = xa;
     double* oth = xb;
     const int sweeps = 6;
     for (int s = 1; s < sweeps; ++s) {
         if (s == 2 || s == sweeps - 1) {
-            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, cur, cur, h->partial);
-            reduce_local(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2));
+            if (rows > 0) hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, cur, cur, h->partial);
+            if (glob) SNS_TRY(reduce_to(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2)));
+            else reduce_local(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2));
         }
+        if (glob) SNS_TRY(exchange_level(h, l, cur));
         launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, zero, omega, nullptr);
         std::swap(cur, oth);
     }
@@ -804,7 +835,9 @@ int pc_setup(sns_ctx* h) {
         if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
             double lam = L.lambda_max;
-            if (rows > 0 && (!(lam > 0.0) || (h->pc_setups & 3) == 0)) SNS_TRY(estimate_lambda_max(h, l, &lam));
+            // (collective when the level's sweeps use exchanged ghost values: every rank takes part, rows or not)
+            if ((rows > 0 || uses_ghosts_in_sweeps(h, l, L)) && (!(lam > 0.0) || (h->pc_setups & 3) == 0))
+                SNS_TRY(estimate_lambda_max(h, l, &lam));
             const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0;
             L.lambda_max = lam;
             if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam);
@@ -961,20 +994,21 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         }
         return SNS_OK;
     }
-    // sweeps per level: the fine level is the expensive one (1 sweep); level 1 and 2 are cheap and are where
-    // plain aggregation needs the smoothing (4 and 6); levels >= 3 are launch-bound (2).  Measured on the
-    // 10 M-tet Jacobian: (1,4,6,2) 40-42 its / 180-186 ms; (1,4,4,4) 45 / 204; (2,2,2,2) 54 / 323.
-    const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
-    int nu = std::max(1, h->opt.amg_nu);
-    if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;
-    else if (ll == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2;
-    else if (ll >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;
+    const int nu = level_nu(h, l);
     const int nswaps = 2 * nu - 1;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
     // distributed: on levels with few rows per rank the sweeps see the neighbours' current iterate (one small
     // exchange per sweep); on the big levels they stay rank-local (ghost values zero) and only the residual is exact
-    const bool sx = L.xg && rows <= h->opt.amg_sweep_exchange_rows;
+    const bool sx = level_sx(h, L);
+    // ... and the sweeps AFTER the coarse-grid correction take the neighbours' corrected iterate as (frozen) ghost
+    // values: with zero ghosts they would see the whole correction as a residual along the partition interfaces
+    const bool px = level_px(h, l, L);
+    const size_t ghost4 = 4 * (size_t)(L.n - rows);
+    if (px && ghost4 > 0) {
+        HIP_TRY(hipMemsetAsync(cur + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(oth + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
+    }
     if (rows > 0) hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
     for (int s = 1; s < nu; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
@@ -997,6 +1031,12 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
                            C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
+    if (px) {
+        SNS_TRY(exchange_level(h, l, cur));
+        if (ghost4 > 0 && nu > 1)
+            HIP_TRY(hipMemcpyAsync(oth + 4 * (size_t)rows, cur + 4 * (size_t)rows, ghost4 * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    }
     for (int s = 0; s < nu; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
@@ -1422,6 +1462,7 @@ void sns_default_options(sns_options* o) {
     o->assembly_fused = 1;
     o->amg_sweep_exchange_rows = 0;
     o->amg_replicate_rows = 65536;
+    o->amg_post_exchange = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1594,7 +1635,8 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     if (!h || !o) return SNS_E_ARG;
     const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix);
     const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
-    const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows);
+    const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows) ||
+                                        (o->amg_post_exchange != h->opt.amg_post_exchange);
     h->opt = *o;
     if (sweep_exchange_changed) {
         // rank-local sweeps rely on ghost tails that are never written (zero); sweeps with exchanges fill them
