@@ -203,6 +203,55 @@ def channel_mesh(cells=(40, 10, 10), *, inner_half_width: float = 0.25, jitter: 
                          "inner_half_width": inner_half_width})
 
 
+def delaunay_duct_mesh(n: int = 8, x_outlet: float = 2.0, *, seed: int = 0, min_quality: float = 1e-3,
+                       tags: dict | None = None) -> TetMesh:
+    """Genuinely unstructured duct mesh: Delaunay tetrahedralisation (scipy) of a jittered point cloud with
+    exact boundary points; slivers (volume / h^3 < ``min_quality``) are dropped where that leaves the
+    domain watertight (they sit on the boundary faces of the convex hull).  Variable valence, arbitrary cell
+    orientation and vertex order -- the kind of input gmsh produces for the reference (DuctStokesFlow.py:36-124)."""
+    from scipy.spatial import Delaunay
+    tags = dict(DUCT_TAGS if tags is None else tags)
+    rng = np.random.default_rng(seed)
+    nx = max(2, int(round(n * x_outlet)))
+    xs, ys, zs = np.linspace(0, x_outlet, nx + 1), np.linspace(-0.5, 0.5, n + 1), np.linspace(-0.5, 0.5, n + 1)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    h = 1.0 / n
+    I, J, K = np.meshgrid(np.arange(nx + 1), np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    # interior points move freely, points on a face only inside that face (edges / corners stay)
+    d = rng.uniform(-0.3, 0.3, size=pts.shape) * h
+    d[:, 0][((I == 0) | (I == nx)).ravel()] = 0.0
+    d[:, 1][((J == 0) | (J == n)).ravel()] = 0.0
+    d[:, 2][((K == 0) | (K == n)).ravel()] = 0.0
+    pts = pts + d
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    X4 = pts[tets]
+    vol = np.abs(np.linalg.det(np.stack([X4[:, 1] - X4[:, 0], X4[:, 2] - X4[:, 0], X4[:, 3] - X4[:, 0]], axis=2))) / 6.0
+    tets = tets[vol > min_quality * h ** 3]
+    lo, hi = (0.0, -0.5, -0.5), (float(x_outlet), 0.5, 0.5)
+    tets = tets.astype(np.int32)
+    fac = _boundary_facets(tets)
+
+    def tagger(on, _cent):
+        t = np.full(fac.shape[0], tags["wall"])
+        t[on["xlo"]] = tags["inlet"]
+        t[on["xhi"]] = tags["outlet"]
+        return t
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    c = pts[fac]
+    tol = 1e-9 * x_outlet
+    on_hull = np.zeros(len(fac), dtype=bool)
+    for ax in range(3):
+        on_hull |= np.all(np.abs(c[:, :, ax] - lo[ax]) < tol, axis=1) | np.all(np.abs(c[:, :, ax] - hi[ax]) < tol, axis=1)
+    if not on_hull.all():
+        raise ValueError("delaunay_duct_mesh: dropping slivers opened the mesh; lower min_quality")
+    if len(np.unique(tets)) != len(pts):
+        raise ValueError("delaunay_duct_mesh: a point lost all its tets")
+    return TetMesh(pts, tets, fac, ft, name="duct-delaunay",
+                   meta={"lo": lo, "hi": hi, "tags": tags, "kind": "duct"})
+
+
 def cavity_mesh(n: int = 16, *, jitter: float = 0.0) -> TetMesh:
     """Unit-cube lid-driven cavity, lid at y=1 (LidDrivenNavierStokesFlow.py:33-43 in 3-D)."""
     tags = dict(CAVITY_TAGS)
