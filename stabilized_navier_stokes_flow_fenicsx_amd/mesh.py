@@ -203,10 +203,10 @@ def channel_mesh(cells=(40, 10, 10), *, inner_half_width: float = 0.25, jitter: 
                          "inner_half_width": inner_half_width})
 
 
-def delaunay_duct_mesh(n: int = 8, x_outlet: float = 2.0, *, seed: int = 0, min_quality: float = 1e-3,
+def delaunay_duct_mesh(n: int = 8, x_outlet: float = 2.0, *, seed: int = 0, min_quality: float = 1e-9,
                        tags: dict | None = None) -> TetMesh:
     """Genuinely unstructured duct mesh: Delaunay tetrahedralisation (scipy) of a jittered point cloud with
-    exact boundary points; slivers (volume / h^3 < ``min_quality``) are dropped where that leaves the
+    exact boundary points; flat tets (volume / h^3 < ``min_quality``) are dropped where that leaves the
     domain watertight (they sit on the boundary faces of the convex hull).  Variable valence, arbitrary cell
     orientation and vertex order -- the kind of input gmsh produces for the reference (DuctStokesFlow.py:36-124)."""
     from scipy.spatial import Delaunay
