@@ -70,7 +70,10 @@ typedef struct sns_ctx* sns_handle;
 #define SNS_SNES_DIVERGED_MAX_IT           -5
 #define SNS_SNES_DIVERGED_LINE_SEARCH      -6
 
-/* solver knobs; sns_default_options() fills the reference's values */
+/* solver knobs; sns_default_options() fills the reference's values.  The shape of the AMG hierarchy (amg_max_levels,
+ * amg_coarse_size, amg_agg_size, amg_replicate_rows) is fixed when it is built -- in sns_create, and again in
+ * sns_attach_comm / sns_attach_team -- so those four must be set in the options passed to sns_create; every other
+ * field can be changed later with sns_set_options. */
 typedef struct {
     double reynolds;        /* Re, nu = 1/Re                         :223            */
     int    ksp_type;        /* SNS_KSP_*                             :77,:199        */
@@ -103,8 +106,9 @@ typedef struct {
     int    amg_replicate_rows; /* multi-GPU: the first AMG level (>= 1) with at most this many GLOBAL rows, and all below,
                                are held and cycled redundantly by every rank (values all-gathered at setup, one
                                all-gather of the right-hand side per cycle, no exchanges below); 0 = off.  Default 65536 */
-    int    amg_post_exchange; /* multi-GPU: 1 (default) = one more ghost exchange per level and cycle, after the coarse-grid
-                               correction, so that the post-smoothing sweeps see the neighbours' corrected iterate */
+    int    amg_post_exchange; /* multi-GPU: 1 (default) = on levels with ONE post-smoothing sweep (the fine level) one more
+                               ghost exchange after the coarse-grid correction, which makes that sweep the exact
+                               global block-Jacobi sweep */
     int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
                                state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
 } sns_options;
