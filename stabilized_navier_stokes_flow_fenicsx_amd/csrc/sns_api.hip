@@ -897,16 +897,22 @@ int pc_setup(sns_ctx* h) {
 }
 
 int vcycle(sns_ctx* h, int l, const double* b, double* x);
-constexpr int GRAPH_LEVEL = 2;     // levels >= 2 of a 10 M-tet hierarchy are ~70 launches of <= 15 us each
+// First level (>= 1) small enough that its kernels are launch-bound rather than bandwidth-bound: it and everything
+// below run as one graph.  10 M tets: level 2 (36 k rows; level 1 has 218 k rows = 46 us per sweep); 1 M tets: level 1.
+inline int serial_graph_level(const sns_ctx* h) {
+    for (int l = 1; l < (int)h->levels.size(); ++l)
+        if (h->levels[l].n <= 150000) return l;
+    return 0;
+}
 
-// Coarse part of the cycle (level GRAPH_LEVEL and below) as ONE hipGraph launch.  Captured on a private
+// Coarse part of the cycle (the graph level and below) as ONE hipGraph launch.  Captured on a private
 // stream (the caller's stream may be the legacy default stream, which cannot be captured), re-captured when
 // the per-level damping or the cycle shape changed.  Distributed runs keep direct launches (the exchange
 // inside the cycle is a host-driven RCCL group).  Any capture failure disables the graph for good.
 int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     const bool dist = h->comm && h->comm->active() && h->comm->nranks > 1;
     // distributed runs: only the replicated tail is free of exchanges and can be captured
-    const int gl = dist ? h->rep_level : GRAPH_LEVEL;
+    const int gl = dist ? h->rep_level : serial_graph_level(h);
     if (gl <= 0 || l != gl || h->graph_disabled || (int)h->levels.size() <= gl + 1) return vcycle(h, l, b, x);
     std::vector<double> sig;
     for (auto& L : h->levels) sig.push_back(L.omega);
