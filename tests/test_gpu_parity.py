@@ -446,6 +446,45 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
         assert outs[0][5] >= 3                                                # fine, distributed level 1, replicated tail
 
 
+@pytest.mark.parametrize("opts", [dict(amg_post_exchange=0, amg_replicate_rows=0),
+                                  dict(amg_post_exchange=1, amg_replicate_rows=0, amg_sweep_exchange_rows=300),
+                                  dict(amg_post_exchange=0, amg_replicate_rows=1 << 20, amg_coarse_size=24),
+                                  dict(amg_post_exchange=1, amg_replicate_rows=1 << 20, amg_coarse_size=24,
+                                       amg_sweep_exchange_rows=1 << 20, ksp_type="fgmres")])
+def test_partitioned_hierarchy_option_combinations(gpu, opts):
+    """Every combination of the multi-GPU hierarchy options (post-correction exchange, per-sweep exchange,
+    replicated tail) solves the same problem to the same fields on a 2 x 2 block partition with corner ghosts."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    m = M.cavity_mesh(14, jitter=0.1)
+    mask, g = B.cavity_bcs(m).flatten()
+    Ps = gpu(m, (mask, g), reynolds=20.0)
+    Us, _ = Ps.stokes_solve()
+    ws, ns = Ps.newton_solve(Us.clone())
+    ws = ws.cpu().numpy()
+    Ps.close()
+    owner = PT.rcb_partition(m.points, 4)
+    team = Team(4)
+
+    def work(rank, team):
+        part = PT.build_local_part(m, mask, g, owner, rank, 4)
+        P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=20.0, part=part, group=team, **opts)
+        U, r = P.stokes_solve()
+        w, n = P.newton_solve(U.clone())
+        out = (part, w.cpu().numpy(), r, n)
+        P.close()
+        return out
+
+    outs = team.run(work)
+    team.close()
+    wg = np.zeros(m.num_dofs)
+    for part, w, r, n in outs:
+        gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
+        wg[gd] = w[:4 * part.n_owned]
+        assert r.reason > 0 and n.reason == ns.reason and n.its == ns.its
+    assert rel(wg, ws) < 1e-7
+
+
 @pytest.mark.parametrize("kind,Re,n", [("cavity", 100.0, 12), ("channel", 30.0, 8)])
 def test_newton_fields_vs_oracle_lu_newton(gpu, kind, Re, n):
     """BASELINE configs 3/4 at reduced size: converged velocity vs the oracle's LU-Newton, < 1e-6 (north_star)."""
