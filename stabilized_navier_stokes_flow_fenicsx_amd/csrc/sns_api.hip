@@ -2007,7 +2007,7 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
                 } else {
                     const int grid = (rows + 63) / 64;
                     // which = 1: production vs variant 1; which = 2: production vs variant 2
-                    if (v && which == 1) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1>), dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                    if (v && which == 1) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
                     else if (v) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
                     else hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
                 }

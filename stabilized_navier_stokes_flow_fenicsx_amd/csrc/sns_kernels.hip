@@ -897,6 +897,13 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
     const int32_t row = (blk * 4 + (tid >> 6)) * 8 + (lane >> 3);
     double acc0 = 0.0, acc1 = 0.0;
     const bool live = row < n_rows;
+    // per-row operands of the epilogue are requested before the block loop (their latency hides behind it)
+    double pre_v = 0.0, pre_x = 0.0;
+    if (live && hf == 0) {
+        if (MODE == SPMV_B_MINUS_AX || MODE == SPMV_JACOBI) pre_v = bvec[4 * (int64_t)row + r];
+        if (MODE == SPMV_AX_DOT) pre_v = dotw[4 * (int64_t)row + r];
+        if (MODE == SPMV_JACOBI) pre_x = x[4 * (int64_t)row + r];
+    }
     {
         // The kernel is bound by VMEM instruction issue, not by bytes, so every step of 4 blocks issues as few
         // loads as possible: ONE index load per quad (lane j fetches colind[k + j]; DPP hands the ids round),
@@ -949,25 +956,25 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
     if (MODE == SPMV_AX) {
         if (live && hf == 0) y[4 * (int64_t)row + r] = acc;
     } else if (MODE == SPMV_B_MINUS_AX) {
-        if (live && hf == 0) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
+        if (live && hf == 0) y[4 * (int64_t)row + r] = pre_v - acc;
     } else if (MODE == SPMV_JACOBI) {
         // y = x + omega * Dinv (b - A x): residual of row component r lives on lanes (r,*);
         // fetch the 4 components of this row's residual with shuffles inside the 8-lane group.
-        const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
+        const double res = live ? (pre_v - acc) : 0.0;      // only the hf == 0 lanes' residuals are fetched below
         const int gbase = lane & ~7;
         const double r0 = __shfl(res, gbase + 0), r1 = __shfl(res, gbase + 2), r2 = __shfl(res, gbase + 4),
                      r3 = __shfl(res, gbase + 6);
         if (live && hf == 0) {
             const double* D = dinv + 16 * (int64_t)row + 4 * r;
             y[4 * (int64_t)row + r] =
-                x[4 * (int64_t)row + r] + omega * (D[0] * r0 + D[1] * r1 + D[2] * r2 + D[3] * r3);
+                pre_x + omega * (D[0] * r0 + D[1] * r1 + D[2] * r2 + D[3] * r3);
         }
     } else if (MODE == SPMV_AX_DOT) {
         // y = A x and partial[block] = sum_rows dotw . y   (fused <r^, A p> of BiCGStab)
         double pr = 0.0;
         if (live && hf == 0) {
             y[4 * (int64_t)row + r] = acc;
-            pr = acc * dotw[4 * (int64_t)row + r];
+            pr = acc * pre_v;
         }
         __shared__ double red[4];
 #pragma unroll
@@ -1012,53 +1019,66 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = lane & 3;
-    // VAR = 1 (A/B harness): every wave walks RG consecutive groups of 16 rows instead of one, so waves live RG
-    // times longer and the launch carries RG times fewer workgroups
-    constexpr int RG = (VAR == 1) ? 4 : 1;
-#pragma unroll 1
-    for (int rg = 0; rg < RG; ++rg) {
-        const int32_t row = ((blk * 4 + (tid >> 6)) * RG + rg) * 16 + (lane >> 2);
-        const bool live = row < n_rows;
-        double acc0 = 0.0, acc1 = 0.0;
-        // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
-        const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
-        const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
-        // Per quad and step of 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids
-        // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
-        // component r of each x block).  VAR = 2 keeps the four broadcast index loads for the A/B harness.
-        int32_t k = s;
-        for (; k + 3 < e; k += 4) {
-            int32_t c0, c1, c2, c3;
-            if (VAR == 2) {
-                c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
-            } else {
-                const int32_t cme = colind[k + r];
-                c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
-            }
-            const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
-            const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
-            const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
-            acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                    (double)a0.w * quad_bcast<3>(g0);
-            acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
-                    (double)a1.w * quad_bcast<3>(g1);
-            acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
-                    (double)a2.w * quad_bcast<3>(g2);
-            acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
-                    (double)a3.w * quad_bcast<3>(g3);
-            vp += 16;
+    const int32_t row = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool live = row < n_rows;
+    double acc0 = 0.0, acc1 = 0.0;
+    // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
+    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
+    // the row's b, x and D^-1 entries are requested BEFORE the block loop, so their latency hides behind it
+    // (-2..3 % against loading them in the epilogue; VAR = 1 keeps the epilogue loads for the A/B harness)
+    double pre_b = 0.0, pre_x = 0.0;
+    double2 pre_d01 = make_double2(0.0, 0.0), pre_d23 = pre_d01;
+    if (VAR != 1 && MODE == SPMV_B_MINUS_AX && live) pre_b = bvec[4 * (int64_t)row + r];
+    if (VAR != 1 && MODE == SPMV_JACOBI && live) {
+        pre_b = bvec[4 * (int64_t)row + r];
+        pre_x = x[4 * (int64_t)row + r];
+        const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
+        pre_d01 = D2[0];
+        pre_d23 = D2[1];
+    }
+    // Per quad and step of 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids
+    // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
+    // component r of each x block).  VAR = 2 keeps the four broadcast index loads for the A/B harness.
+    int32_t k = s;
+    for (; k + 3 < e; k += 4) {
+        int32_t c0, c1, c2, c3;
+        if (VAR == 2) {
+            c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
+        } else {
+            const int32_t cme = colind[k + r];
+            c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
         }
-        for (; k < e; ++k) {
-            const float4 a0 = vp[0];
-            const double g0 = x[4 * (int64_t)colind[k] + r];
-            acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                    (double)a0.w * quad_bcast<3>(g0);
-            vp += 4;
-        }
-        const double acc = acc0 + acc1;                 // (A x)[4*row + r]
-        if (MODE == SPMV_B_MINUS_AX) {
-            if (live) y[4 * (int64_t)row + r] = bvec[4 * (int64_t)row + r] - acc;
-        } else if (MODE == SPMV_JACOBI) {
+        const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
+        const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
+        const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
+        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                (double)a0.w * quad_bcast<3>(g0);
+        acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
+                (double)a1.w * quad_bcast<3>(g1);
+        acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
+                (double)a2.w * quad_bcast<3>(g2);
+        acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
+                (double)a3.w * quad_bcast<3>(g3);
+        vp += 16;
+    }
+    for (; k < e; ++k) {
+        const float4 a0 = vp[0];
+        const double g0 = x[4 * (int64_t)colind[k] + r];
+        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
+                (double)a0.w * quad_bcast<3>(g0);
+        vp += 4;
+    }
+    const double acc = acc0 + acc1;                 // (A x)[4*row + r]
+    if (MODE == SPMV_B_MINUS_AX) {
+        if (live) y[4 * (int64_t)row + r] = (VAR != 1 ? pre_b : bvec[4 * (int64_t)row + r]) - acc;
+    } else if (MODE == SPMV_JACOBI) {
+        if (VAR != 1) {
+            const double res = live ? (pre_b - acc) : 0.0;
+            const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
+            if (live)
+                y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
+        } else {
             const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
             const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
             if (live) {
