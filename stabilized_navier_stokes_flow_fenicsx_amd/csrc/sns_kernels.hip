@@ -1026,11 +1026,11 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
     const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
     // the row's b, x and D^-1 entries are requested BEFORE the block loop, so their latency hides behind it
-    // (-2..3 % against loading them in the epilogue; VAR = 1 keeps the epilogue loads for the A/B harness)
+    // (-2..4 % against loading them in the epilogue)
     double pre_b = 0.0, pre_x = 0.0;
     double2 pre_d01 = make_double2(0.0, 0.0), pre_d23 = pre_d01;
-    if (VAR != 1 && MODE == SPMV_B_MINUS_AX && live) pre_b = bvec[4 * (int64_t)row + r];
-    if (VAR != 1 && MODE == SPMV_JACOBI && live) {
+    if (MODE == SPMV_B_MINUS_AX && live) pre_b = bvec[4 * (int64_t)row + r];
+    if (MODE == SPMV_JACOBI && live) {
         pre_b = bvec[4 * (int64_t)row + r];
         pre_x = x[4 * (int64_t)row + r];
         const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
@@ -1041,12 +1041,21 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
     // component r of each x block).  VAR = 2 keeps the four broadcast index loads for the A/B harness.
     int32_t k = s;
+    // VAR = 1 (A/B harness): the ids of the NEXT step are requested one step ahead (index -> x gather is a
+    // dependent chain of two memory round trips per step otherwise)
+    int32_t cnext = (VAR == 1 && k + 3 < e) ? colind[k + r] : 0;
     for (; k + 3 < e; k += 4) {
         int32_t c0, c1, c2, c3;
         if (VAR == 2) {
             c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
         } else {
-            const int32_t cme = colind[k + r];
+            int32_t cme;
+            if (VAR == 1) {
+                cme = cnext;
+                cnext = (k + 7 < e) ? colind[k + 4 + r] : 0;
+            } else {
+                cme = colind[k + r];
+            }
             c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
         }
         const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
@@ -1071,23 +1080,12 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     }
     const double acc = acc0 + acc1;                 // (A x)[4*row + r]
     if (MODE == SPMV_B_MINUS_AX) {
-        if (live) y[4 * (int64_t)row + r] = (VAR != 1 ? pre_b : bvec[4 * (int64_t)row + r]) - acc;
+        if (live) y[4 * (int64_t)row + r] = pre_b - acc;
     } else if (MODE == SPMV_JACOBI) {
-        if (VAR != 1) {
-            const double res = live ? (pre_b - acc) : 0.0;
-            const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
-            if (live)
-                y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
-        } else {
-            const double res = live ? (bvec[4 * (int64_t)row + r] - acc) : 0.0;
-            const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
-            if (live) {
-                const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
-                const double2 d01 = D2[0], d23 = D2[1];
-                y[4 * (int64_t)row + r] =
-                    x[4 * (int64_t)row + r] + omega * (d01.x * r0 + d01.y * r1 + d23.x * r2 + d23.y * r3);
-            }
-        }
+        const double res = live ? (pre_b - acc) : 0.0;
+        const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
+        if (live)
+            y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
     }
 }
 #define SNS_INST_SPMV32(M, F, N)                                                                              \
