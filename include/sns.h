@@ -71,9 +71,9 @@ typedef struct sns_ctx* sns_handle;
 #define SNS_SNES_DIVERGED_LINE_SEARCH      -6
 
 /* solver knobs; sns_default_options() fills the reference's values.  The shape of the AMG hierarchy (amg_max_levels,
- * amg_coarse_size, amg_agg_size, amg_replicate_rows) is fixed when it is built -- in sns_create, and again in
- * sns_attach_comm / sns_attach_team -- so those four must be set in the options passed to sns_create; every other
- * field can be changed later with sns_set_options. */
+ * amg_coarse_size, amg_agg_size, amg_replicate_rows) is fixed when it is built, lazily at the first sns_pc_setup or
+ * solve (after sns_attach_comm, if any): those four must be set before that; every other field can be changed at any
+ * time with sns_set_options. */
 typedef struct {
     double reynolds;        /* Re, nu = 1/Re                         :223            */
     int    ksp_type;        /* SNS_KSP_*                             :77,:199        */
