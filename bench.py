@@ -132,7 +132,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=", 1)
         opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
-    weak = world > 1 and not args.strong
+    weak = (world > 1 or force_dist) and not args.strong      # SNS_FORCE_DIST=1: rehearse the N>1 code path with one rank
     if weak:
         # weak scaling: the duct is refined uniformly so that every GPU keeps about the single-GPU share
         # (--cells tets): cells x N^(1/3) per direction, same geometry and Re.  Ranks own x-slabs; each rank
