@@ -254,6 +254,13 @@ def test_full_size_properties(gpu, cells, Re):
     P.jacobian(None, "stokes", residual_out=F0)
     r = P.spmv(U) + F0                                                # A U - b, b = -F(0)
     assert float(r.norm() / F0.norm()) < 1e-7
+    # known answer at full size: fully developed square-duct profile half-way down the duct, u_max / u_mean = 2.0963
+    # (series solution; the stabilised P1-P1 discretisation converges to it with O(h^2))
+    nx, ny, nz = cells
+    sx = (ny + 1) * (nz + 1)
+    ux = U.view(-1, 4)[(nx // 2) * sx:(nx // 2 + 1) * sx, 0]
+    ratio = float(ux.max() / (ux.sum() / (ny * nz)))                  # trapezoid rule: wall values are zero
+    assert abs(ratio - 2.0963) < (0.03 if ny < 50 else 0.01), ratio
     gen = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn(P.ndof, dtype=torch.float64, device="cuda", generator=gen)
     y = torch.randn(P.ndof, dtype=torch.float64, device="cuda", generator=gen)
