@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host-side symbolic setup (BSR pattern,
     # gather lists: OpenMP in libsns.so) wants this rank's share of the cores.  Must happen before libgomp loads.
