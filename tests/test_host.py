@@ -268,3 +268,18 @@ def test_boundary_traction_force_known_answers_and_oracle():
     for tag in (t["wall"], t["inlet"]):
         ref = traction_force_loops(mj.points, mj.tets, mj.facets, mj.find(tag), wr, nu)
         assert np.allclose(Fn.boundary_traction_force(mj, wr, nu, tag), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_helpers_without_gpu():
+    """bench.py pieces that need no GPU: the PMC traffic figure comes from the committed profiles (latest round),
+    defaults finish within minutes (K=4, W=1, N=1), and the module never touches the oracle at import time."""
+    import importlib, sys
+    sys.modules.pop("bench", None)
+    before = {m for m in sys.modules if m == "oracle" or m.startswith("oracle.")}
+    bench = importlib.import_module("bench")
+    after = {m for m in sys.modules if m == "oracle" or m.startswith("oracle.")}
+    assert after == before                                   # cpu_baseline imports the oracle lazily, only when it runs
+    t = bench.pmc_traffic("k_spmv_f32<2, 1")
+    assert t is not None and 2.0e9 < t < 3.0e9               # 2.14 GB algorithmic, ~2.4 GB measured
+    assert bench.pmc_traffic("no_such_kernel") is None
+    assert bench.HBM_PEAK_GBS == 8000.0
