@@ -1884,6 +1884,8 @@ int sns_newton_solve(sns_handle h, double* w, int* its_out, int* reason_out, int
         }
         if (!ok) { reason = (gn == gn) ? SNS_SNES_DIVERGED_LINE_SEARCH : SNS_SNES_DIVERGED_FNORM_NAN; break; }
         HIP_TRY(hipMemcpyAsync(w, wn, ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // Dirichlet dofs within round-off of their data become exact (no lifting term from here on, :65)
+        hipLaunchKernelGGL(k_snap_bc, dim3(vec_grid(ld)), dim3(256), 0, h->stream, ld, h->bc_mask, h->bc_val, w);
         double xnorm;
         SNS_TRY(norm2(h, w, &xnorm));
         f = gn;

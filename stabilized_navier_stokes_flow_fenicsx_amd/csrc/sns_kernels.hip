@@ -471,10 +471,8 @@ __device__ __forceinline__ void tet_block_accumulate(const int4 tv, const double
         visc[j] = gu[j][0] * ga[0] + gu[j][1] * ga[1] + gu[j][2] * ga[2];                   // (grad u) g_a
         guga[j] = corrected ? (ga[0] * gu[0][j] + ga[1] * gu[1][j] + ga[2] * gu[2][j]) : visc[j];
     }
-    double blk[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) blk[e] = 0.0;
-    double Rq[4] = {0.0, 0.0, 0.0, 0.0};
+    // the quadrature weight wd is folded into the per-point coefficients, so every term lands directly in the
+    // caller's accumulators (no per-contribution block)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         double u[3] = {0.0, 0.0, 0.0}, p = 0.0;
@@ -501,53 +499,50 @@ __device__ __forceinline__ void tet_block_accumulate(const int4 tv, const double
         const double sa = r[0] * ga[0] + r[1] * ga[1] + r[2] * ga[2];
         const double ugb = u[0] * gb[0] + u[1] * gb[1] + u[2] * gb[2];
         const double uga = u[0] * ga[0] + u[1] * ga[1] + u[2] * ga[2];
-        const double t3 = tau * tau * tau;
-        double cu[3], cg[3];
+        const double tw = wd * tau;                            // weighted tau
+        const double t3w = tw * tau * tau;
+        const double wpb = wd * pb, wpa = wd * pa;
+        double cu[3], cg[3];                                   // both carry the weight
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double dtau = -t3 * pb * Gu[j];
-            const double dnuL = (tau * itrG) * pb * Gu[j];
-            cg[j] = dnuL * divu + nuL * gb[j];
-            cu[j] = corrected ? dtau : dtau * sa + tau * (u[j] * gab + pb * guga[j]);
+            const double dtau = -t3w * pb * Gu[j];
+            const double dnuL = (tw * itrG) * pb * Gu[j];
+            cg[j] = dnuL * divu + (wd * nuL) * gb[j];
+            cu[j] = corrected ? dtau : dtau * sa + tw * (u[j] * gab + pb * guga[j]);
         }
         if (!corrected) {
-            const double A1 = pa * ugb + nu * gab + tau * sa * pb;
+            const double A1 = wpa * ugb + (wd * nu) * gab + tw * sa * pb;
+            const double ppw = wpa * pb, tgw = tw * gab;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) blk[4 * i + j] += pa * pb * gu[i][j] + u[i] * cu[j] + ga[i] * cg[j];
-                blk[5 * i] += A1;
-                blk[4 * i + 3] += -pb * ga[i] + tau * u[i] * gab;
-                blk[12 + i] += pa * gb[i] + cu[i];
+                for (int j = 0; j < 3; ++j) acc[4 * i + j] += ppw * gu[i][j] + u[i] * cu[j] + ga[i] * cg[j];
+                acc[5 * i] += A1;
+                acc[4 * i + 3] += tgw * u[i] - wpb * ga[i];
+                acc[12 + i] += wpa * gb[i] + cu[i];
             }
-            blk[15] += tau * gab;
+            acc[15] += tgw;
         } else {
-            const double A1 = pa * ugb + nu * gab + tau * uga * ugb;
+            const double A1 = wpa * ugb + (wd * nu) * gab + tw * uga * ugb;
+            const double cgu = wpa * pb + tw * uga * pb;       // coefficient of gu[i][j]
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    blk[4 * i + j] += pa * pb * gu[i][j] + cu[j] * uga * r[i] + tau * pb * ga[j] * r[i] +
-                                      tau * uga * pb * gu[i][j] + ga[i] * cg[j];
-                blk[5 * i] += A1;
-                blk[4 * i + 3] += -pb * ga[i] + tau * uga * gb[i];
-                blk[12 + i] += pa * gb[i] + cu[i] * sa + tau * (ugb * ga[i] + pb * guga[i]);
+                    acc[4 * i + j] += cgu * gu[i][j] + (cu[j] * uga + tw * pb * ga[j]) * r[i] + ga[i] * cg[j];
+                acc[5 * i] += A1;
+                acc[4 * i + 3] += tw * uga * gb[i] - wpb * ga[i];
+                acc[12 + i] += wpa * gb[i] + cu[i] * sa + tw * (ugb * ga[i] + pb * guga[i]);
             }
-            blk[15] += tau * gab;
+            acc[15] += tw * gab;
         }
         if (want_res) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                Rq[i] += conv[i] * pa + nu * visc[i] - p * ga[i] + (corrected ? tau * uga * r[i] : tau * u[i] * sa) +
-                         nuL * divu * ga[i];
-            Rq[3] += pa * divu + tau * sa;
+                Ra[i] += wpa * conv[i] + (wd * nu) * visc[i] - (wd * p) * ga[i] +
+                         (corrected ? tw * uga * r[i] : tw * u[i] * sa) + (wd * nuL) * divu * ga[i];
+            Ra[3] += wpa * divu + tw * sa;
         }
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += wd * blk[e];
-    if (want_res) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Ra[c] += wd * Rq[c];
     }
 }
 
@@ -1223,6 +1218,17 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(int nblocks, int nred, co
         __syncthreads();
     }
     if (threadIdx.x == 0) out[(int64_t)blockIdx.x * nred + k] = red[0];
+}
+
+// Dirichlet dofs that already agree with the prescribed value to round-off are set to it exactly, so that the
+// state keeps qualifying for the lifting-free assembly paths (which test bitwise equality)
+__global__ __launch_bounds__(256) void k_snap_bc(int64_t ndof, const uint8_t* __restrict__ bc_mask,
+                                                 const double* __restrict__ bc_val, double* __restrict__ w) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndof; i += (int64_t)gridDim.x * blockDim.x)
+        if (bc_mask[i]) {
+            const double g = bc_val[i];
+            if (fabs(w[i] - g) <= 1e-12 * fmax(1.0, fabs(g))) w[i] = g;
+        }
 }
 
 // partial[block] = number of Dirichlet dofs whose current value differs from the prescribed one
