@@ -6,6 +6,9 @@ cells = eval(sys.argv[1]) if len(sys.argv) > 1 else (300, 75, 75)
 m = M.duct_mesh(cells, 4.0)
 P = FlowProblem(m, B.duct_bcs(m), reynolds=200.0)
 U, r = P.stokes_solve()
+# the Stokes field meets the Dirichlet data only to solver tolerance; the scratch-free path wants them exact
+mask, g = B.duct_bcs(m).flatten()
+U[torch.from_numpy(mask.astype(bool)).cuda()] = torch.from_numpy(g[mask.astype(bool)]).cuda()
 for rep in range(2):
     for fused in (0, 1):
         P.set_options(assembly_fused=fused)
