@@ -1803,7 +1803,15 @@ int sns_stokes_solve(sns_handle h, double* U, int* ksp_its, int* reason, double*
     SNS_TRY(timed_assemble(h, SNS_FORM_STOKES, nullptr, h->nw_F, true));
     hipLaunchKernelGGL(k_scale_copy, dim3(vec_grid(nd)), dim3(256), 0, h->stream, nd, -1.0, h->nw_F, h->nw_F);
     HIP_TRY(hipMemsetAsync(U, 0, nd * sizeof(double), h->stream));
-    return krylov(h, h->nw_F, U, ksp_its, reason, rnorm);
+    SNS_TRY(krylov(h, h->nw_F, U, ksp_its, reason, rnorm));
+    // the Dirichlet rows are identity rows: the reference's ILU-preconditioned solve returns them exactly, a Krylov
+    // method under AMG only to its tolerance -- a converged solve hands back the exact data as well
+    if (*reason > 0) {
+        hipLaunchKernelGGL(k_snap_bc, dim3(vec_grid(nd)), dim3(256), 0, h->stream, nd, h->bc_mask, h->bc_val,
+                           1e300, U);
+        SNS_TRY(sync_stream(h));
+    }
+    return SNS_OK;
 }
 
 int sns_newton_solve(sns_handle h, double* w, int* its_out, int* reason_out, int* total_ksp, double* hist,
@@ -1885,7 +1893,7 @@ int sns_newton_solve(sns_handle h, double* w, int* its_out, int* reason_out, int
         if (!ok) { reason = (gn == gn) ? SNS_SNES_DIVERGED_LINE_SEARCH : SNS_SNES_DIVERGED_FNORM_NAN; break; }
         HIP_TRY(hipMemcpyAsync(w, wn, ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         // Dirichlet dofs within round-off of their data become exact (no lifting term from here on, :65)
-        hipLaunchKernelGGL(k_snap_bc, dim3(vec_grid(ld)), dim3(256), 0, h->stream, ld, h->bc_mask, h->bc_val, w);
+        hipLaunchKernelGGL(k_snap_bc, dim3(vec_grid(ld)), dim3(256), 0, h->stream, ld, h->bc_mask, h->bc_val, 1e-12, w);
         double xnorm;
         SNS_TRY(norm2(h, w, &xnorm));
         f = gn;

@@ -1223,11 +1223,12 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(int nblocks, int nred, co
 // Dirichlet dofs that already agree with the prescribed value to round-off are set to it exactly, so that the
 // state keeps qualifying for the lifting-free assembly paths (which test bitwise equality)
 __global__ __launch_bounds__(256) void k_snap_bc(int64_t ndof, const uint8_t* __restrict__ bc_mask,
-                                                 const double* __restrict__ bc_val, double* __restrict__ w) {
+                                                 const double* __restrict__ bc_val, double rel_tol,
+                                                 double* __restrict__ w) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndof; i += (int64_t)gridDim.x * blockDim.x)
         if (bc_mask[i]) {
             const double g = bc_val[i];
-            if (fabs(w[i] - g) <= 1e-12 * fmax(1.0, fabs(g))) w[i] = g;
+            if (fabs(w[i] - g) <= rel_tol * fmax(1.0, fabs(g))) w[i] = g;
         }
 }
 
