@@ -79,6 +79,7 @@ struct sns_ctx {
     int64_t *nt_ptr = nullptr, *c_ptr = nullptr;
     int32_t *nt_idx = nullptr, *c_idx = nullptr;
     int32_t* od_order = nullptr;       // off-diagonal slots, locally sorted by contribution count (scratch-free assembly)
+    double* gext = nullptr;            // Dirichlet data extended by zero (the state the Stokes lifting term is taken at)
     int64_t n_od = 0;
     double *Ke = nullptr, *Fe = nullptr;
     // operator hierarchy; levels[0] is the assembled fine operator
@@ -644,19 +645,35 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         fast_residual = (nviol == 0.0);
     }
     Level& L = h->levels[0];
+    if (form == SNS_FORM_STOKES && !w && want_matrix && h->opt.assembly_fused && h->E > 0) {
+        // the Stokes system of solve_stokes_problem (:197-218): constant element blocks, right-hand side F(0) =
+        // lifting A0[:,B] g (row a of A0 applied to the Dirichlet data extended by zero), F_B = -g
+        const unsigned go = (unsigned)((h->n_od + 255) / 256);
+        const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
+        hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_STOKES, false>), dim3(go), dim3(256), 0, h->stream, h->n_od,
+                           h->od_order, h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->tets, h->pts, h->gext,
+                           h->bc_mask, nu, L.vals);
+        hipLaunchKernelGGL((k_fused_diag<SNS_FORM_STOKES, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag,
+                           h->c_ptr, h->c_idx, h->tets, h->pts, h->gext, h->bc_mask, h->bc_val, nu, L.vals, F);
+        h->has_matrix = true;
+        h->pc_ready = false;
+        h->matrix_form = form;
+        HIP_TRY(hipGetLastError());
+        return SNS_OK;
+    }
     if (fast_residual && want_matrix) {
         // scratch-free path: every BSR block (and every node residual) is computed by the lanes that own it
         const unsigned go = (unsigned)((h->n_od + 255) / 256);
         const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
         if (!h->opt.corrected_convection) {
-            hipLaunchKernelGGL((k_fused_offdiag<false>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
+            hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_NS, false>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
                                h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
-            hipLaunchKernelGGL((k_fused_diag<false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+            hipLaunchKernelGGL((k_fused_diag<SNS_FORM_NS, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
                                h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
         } else {
-            hipLaunchKernelGGL((k_fused_offdiag<true>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
+            hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_NS, true>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
                                h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
-            hipLaunchKernelGGL((k_fused_diag<true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+            hipLaunchKernelGGL((k_fused_diag<SNS_FORM_NS, true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
                                h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
         }
         h->has_matrix = true;
@@ -1518,6 +1535,11 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
     HIP_TRY(hipMemcpy(h->bc_mask, bc_mask, (size_t)4 * n_nodes, hipMemcpyHostToDevice));
     SNS_TRY(dev_alloc(&h->bc_val, (size_t)4 * n_nodes));
     HIP_TRY(hipMemcpy(h->bc_val, bc_val, (size_t)4 * n_nodes * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<double> ge((size_t)4 * n_nodes);
+        for (size_t i = 0; i < ge.size(); ++i) ge[i] = bc_mask[i] ? bc_val[i] : 0.0;
+        SNS_TRY(dev_upload(&h->gext, ge, nullptr));
+    }
     SNS_TRY(dev_upload(&h->nt_ptr, M.nt_ptr, nullptr));
     SNS_TRY(dev_upload(&h->nt_idx, M.nt_idx, nullptr));
     SNS_TRY(dev_upload(&h->c_ptr, M.c_ptr, nullptr));
@@ -1604,7 +1626,7 @@ int sns_destroy(sns_handle h) {
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(h->tets); fr(h->pts); fr(h->bc_mask); fr(h->bc_val);
-    fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->Ke); fr(h->Fe);
+    fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->gext); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32);

@@ -16,11 +16,11 @@ template <int FORM, bool corrected>
 __global__ void k_element(int64_t n_tets, const int32_t* tets, const double* pts, const double* w,
                           const uint8_t* bc_mask, const double* bc_val, double nu, int store_K, double* Ke,
                           double* Fe);
-template <bool corrected>
+template <int FORM, bool corrected>
 __global__ void k_fused_offdiag(int64_t n_od, const int32_t* od_order, const int64_t* c_ptr, const int32_t* c_idx, const int32_t* slot_row,
                                 const int32_t* colind, const int32_t* tets, const double* pts, const double* w,
                                 const uint8_t* bc_mask, double nu, double* vals);
-template <bool corrected>
+template <int FORM, bool corrected>
 __global__ void k_fused_diag(int32_t n_rows, const int32_t* diag, const int64_t* c_ptr, const int32_t* c_idx,
                              const int32_t* tets, const double* pts, const double* w, const uint8_t* bc_mask,
                              const double* bc_val, double nu, double* vals, double* F);

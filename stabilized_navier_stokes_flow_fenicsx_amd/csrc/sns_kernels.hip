@@ -546,8 +546,95 @@ __device__ __forceinline__ void tet_block_accumulate(const int4 tv, const double
     }
 }
 
+// Stokes form (:160-172): block (a,b) of the constant element matrix and, for the diagonal kernel, row a of
+// A0 w (w = the Dirichlet data extended by zero: the lifting term of the right-hand side, :65 with x = 0).
+__device__ __forceinline__ void tet_block_accumulate_stokes(const int4 tv, const double* __restrict__ pts,
+                                                            const double* __restrict__ w, int a, int b, bool want_res,
+                                                            double acc[16], double Ra[4]) {
+    const int32_t nd[4] = {tv.x, tv.y, tv.z, tv.w};
+    double X[4][3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double* pp = pts + 3 * (int64_t)nd[v];
+        X[v][0] = pp[0]; X[v][1] = pp[1]; X[v][2] = pp[2];
+    }
+    double J[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = X[1][i] - X[0][i];
+        J[i][1] = X[2][i] - X[0][i];
+        J[i][2] = X[3][i] - X[0][i];
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double id = 1.0 / det;
+    double K[3][3];
+    K[0][0] = c00 * id; K[1][0] = c01 * id; K[2][0] = c02 * id;
+    K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+    K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+    K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+    K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    double g[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        g[1][j] = K[0][j]; g[2][j] = K[1][j]; g[3][j] = K[2][j];
+        g[0][j] = -(K[0][j] + K[1][j] + K[2][j]);
+    }
+    double h2 = 0.0;                                   // CellDiameter^2 (:168): longest edge
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = v + 1; u < 4; ++u) {
+            const double d0 = X[u][0] - X[v][0], d1 = X[u][1] - X[v][1], d2 = X[u][2] - X[v][2];
+            h2 = fmax(h2, d0 * d0 + d1 * d1 + d2 * d2);
+        }
+    const double wd = fabs(det) * (1.0 / 24.0), vol = 4.0 * wd, muT = 0.2 * h2;       // :169
+    double ga[3], gb[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ga[j] = a == 0 ? g[0][j] : (a == 1 ? g[1][j] : (a == 2 ? g[2][j] : g[3][j]));
+        gb[j] = b == 0 ? g[0][j] : (b == 1 ? g[1][j] : (b == 2 ? g[2][j] : g[3][j]));
+    }
+    const double gab = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acc[5 * i] += vol * gab;                        // (grad u, grad v)
+        acc[4 * i + 3] += -wd * ga[i];                  // -(p, div v)
+        acc[12 + i] += wd * gb[i];                      // +(div u, q)
+    }
+    acc[15] += muT * vol * gab;                         // mu_T (grad p, grad q)
+    if (want_res) {
+        double gu[3][3], gp[3], psum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            gp[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gu[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double* wv = w + 4 * (int64_t)nd[v];
+            psum += wv[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gp[j] += wv[3] * g[v][j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gu[i][j] += wv[i] * g[v][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            Ra[i] += vol * (gu[i][0] * ga[0] + gu[i][1] * ga[1] + gu[i][2] * ga[2]) - wd * ga[i] * psum;
+        Ra[3] += wd * (gu[0][0] + gu[1][1] + gu[2][2]) + muT * vol * (gp[0] * ga[0] + gp[1] * ga[1] + gp[2] * ga[2]);
+    }
+}
+
 // off-diagonal BSR blocks: one lane per slot, slots taken from the host's count-sorted list
-template <bool corrected>
+template <int FORM, bool corrected>
 __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32_t* __restrict__ od_order,
                                                        const int64_t* __restrict__ c_ptr,
                                                        const int32_t* __restrict__ c_idx,
@@ -581,7 +668,8 @@ __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32
             id = c_idx[k];
             tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
         }
-        tet_block_accumulate<corrected>(tvc, pts, w, nu, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
+        if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
+        else tet_block_accumulate<corrected>(tvc, pts, w, nu, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
     }
     const uchar4 mr = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)row);
     const uchar4 mc = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)col);
@@ -597,7 +685,7 @@ __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32
 }
 
 // diagonal blocks + node residuals: 4 lanes per node share the ~24 incident tets, DPP quad sums in a fixed order
-template <bool corrected>
+template <int FORM, bool corrected>
 __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_t* __restrict__ diag,
                                                     const int64_t* __restrict__ c_ptr,
                                                     const int32_t* __restrict__ c_idx,
@@ -631,7 +719,8 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
                 id = c_idx[k];
                 tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
             }
-            tet_block_accumulate<corrected>(tvc, pts, w, nu, a, a, true, acc, R);
+            if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, a, a, true, acc, R);
+            else tet_block_accumulate<corrected>(tvc, pts, w, nu, a, a, true, acc, R);
         }
     }
     // quad sums: (l0 + l1) + (l2 + l3), identical on every lane
@@ -666,18 +755,19 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
     if (F) {
         const int64_t dof = 4 * node + q;
         const double rq = q == 0 ? R[0] : (q == 1 ? R[1] : (q == 2 ? R[2] : R[3]));
-        F[dof] = bc_mask[dof] ? (w[dof] - bc_val[dof]) : rq;
+        F[dof] = bc_mask[dof] ? ((FORM == SNS_FORM_STOKES ? 0.0 : w[dof]) - bc_val[dof]) : rq;
     }
 }
-#define SNS_INST_FUSED(C)                                                                                          \
-    template __global__ void k_fused_offdiag<C>(int64_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
+#define SNS_INST_FUSED(FM, C)                                                                                      \
+    template __global__ void k_fused_offdiag<FM, C>(int64_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
                                                 const int32_t*, const int32_t*, const double*, const double*,       \
                                                 const uint8_t*, double, double*);                                   \
-    template __global__ void k_fused_diag<C>(int32_t, const int32_t*, const int64_t*, const int32_t*,               \
+    template __global__ void k_fused_diag<FM, C>(int32_t, const int32_t*, const int64_t*, const int32_t*,               \
                                              const int32_t*, const double*, const double*, const uint8_t*,          \
                                              const double*, double, double*, double*);
-SNS_INST_FUSED(false)
-SNS_INST_FUSED(true)
+SNS_INST_FUSED(SNS_FORM_NS, false)
+SNS_INST_FUSED(SNS_FORM_NS, true)
+SNS_INST_FUSED(SNS_FORM_STOKES, false)
 
 // Residual-only element pass for states that already satisfy the Dirichlet data (no lifting term):
 // ONE LANE PER TET, every lane busy (the fused kernel keeps 12 of 16 lanes idle in its per-point

@@ -63,10 +63,13 @@ def test_element_kernel_against_golden_literal_forms(gpu):
             assert rel(P.to_scipy().toarray(), g[Jk][i]) < 1e-12
             assert rel(F.cpu().numpy(), g[Fk][i]) < 1e-12
             P.close()
-        P = gpu(m, none, pc_type="bjacobi")
+        P = gpu(m, none, pc_type="bjacobi", assembly_fused=0)
         P.jacobian(None, "stokes")
         Ke = P.element_matrices().cpu().numpy()[0]
         assert rel(Ke.transpose(0, 2, 1, 3).reshape(16, 16), s["A"][i]) < 1e-12
+        P.set_options(assembly_fused=1)                       # scratch-free Stokes blocks
+        P.jacobian(None, "stokes")
+        assert rel(P.to_scipy().toarray(), s["A"][i]) < 1e-12
         P.close()
 
 
@@ -653,6 +656,16 @@ def test_fast_residual_path_when_bcs_hold(gpu, corrected):
     if not corrected:
         Jo = asm.assemble_ns(m.points, m.tets, w, 17.0, mask, g)[0]
         assert abs(J_sf - Jo).max() < 1e-12 * abs(Jo).max()
+        # Stokes system (matrix + lifting right-hand side F(0)) on both assembly paths and vs the oracle
+        sysS = []
+        for fused in (0, 1):
+            P.set_options(assembly_fused=fused)
+            Fs = P.zeros()
+            P.jacobian(None, "stokes", residual_out=Fs)
+            sysS.append((P.to_scipy(), Fs.cpu().numpy()))
+        Ao, bo = asm.assemble_stokes(m.points, m.tets, mask, g)
+        assert abs(sysS[1][0] - sysS[0][0]).max() < 1e-13 * abs(Ao).max() and abs(sysS[1][0] - Ao).max() < 1e-12 * abs(Ao).max()
+        assert rel(sysS[1][1], sysS[0][1]) < 1e-13
     w2 = w.copy(); w2[np.nonzero(Bm)[0][0]] += 0.3               # one violated dof -> general path with lifting
     if not corrected:
         assert rel(P.residual(_dev(w2), "ns").cpu().numpy(), asm.residual_ns(m.points, m.tets, w2, 17.0, mask, g)) < 1e-12
