@@ -16,7 +16,8 @@
 namespace sns {
 
 void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, HostAssemblyMaps& M) {
-    if (E * 16 > (int64_t)INT32_MAX) throw std::runtime_error("mesh too large for int32 element-block ids");
+    // element-block ids tet*16 + a*4 + b are stored as UNSIGNED 32-bit values: up to 2^28 = 268 M tets
+    if (E * 16 > (int64_t)UINT32_MAX) throw std::runtime_error("mesh too large for 32-bit element-block ids (268 M tets)");
     // ---- node -> incident (tet, a) ------------------------------------------
     M.nt_ptr.assign((size_t)n + 1, 0);
     for (int64_t t = 0; t < E; ++t)
@@ -107,7 +108,8 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
                 for (int b = 0; b < 4; ++b) {
                     int32_t j = (int32_t)(std::lower_bound(cb, cb + len, tv[b]) - cb);
                     int64_t s = P.rowptr[i] + j;
-                    M.c_idx[(size_t)(M.c_ptr[s] + fill[j]++)] = (ta >> 2) * 16 + (ta & 3) * 4 + b;
+                    M.c_idx[(size_t)(M.c_ptr[s] + fill[j]++)] =
+                        (int32_t)((uint32_t)(ta >> 2) * 16u + (uint32_t)((ta & 3) * 4 + b));
                 }
             }
         }

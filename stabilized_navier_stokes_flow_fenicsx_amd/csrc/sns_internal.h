@@ -23,7 +23,7 @@ struct HostAssemblyMaps {
     std::vector<int32_t> nt_idx;         // 4*E   (tet*4+a fits int32 up to 536M tets)
     // BSR slot -> contributing element blocks (tet*16 + a*4 + b), fixed order
     std::vector<int64_t> c_ptr;          // nnzb+1
-    std::vector<int32_t> c_idx;          // 16*E  (tet*16+ab fits int32 up to 134M tets)
+    std::vector<int32_t> c_idx;          // 16*E  (tet*16+ab as an UNSIGNED 32-bit pattern: up to 268 M tets)
 };
 
 struct HostAggregation {

@@ -655,17 +655,17 @@ __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32
     // computed, so only the coordinate/state gather latency sits on the critical path
     const int64_t k1 = c_ptr[s + 1];
     int64_t k = c_ptr[s];
-    int32_t id = 0;
+    uint32_t id = 0;                                 // tet*16 + a*4 + b, unsigned (up to 268 M tets)
     int4 tv = make_int4(0, 0, 0, 0);
     if (k < k1) {
-        id = c_idx[k];
+        id = (uint32_t)c_idx[k];
         tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
     }
     while (k < k1) {
-        const int32_t idc = id;
+        const uint32_t idc = id;
         const int4 tvc = tv;
         if (++k < k1) {
-            id = c_idx[k];
+            id = (uint32_t)c_idx[k];
             tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
         }
         if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
@@ -705,10 +705,10 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
         s = diag[node];
         const int64_t k1 = c_ptr[s + 1];
         int64_t k = c_ptr[s] + q;
-        int32_t id = 0;
+        uint32_t id = 0;
         int4 tv = make_int4(0, 0, 0, 0);
         if (k < k1) {
-            id = c_idx[k];
+            id = (uint32_t)c_idx[k];
             tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
         }
         while (k < k1) {
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
             const int4 tvc = tv;
             k += 4;
             if (k < k1) {
-                id = c_idx[k];
+                id = (uint32_t)c_idx[k];
                 tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
             }
             if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, a, a, true, acc, R);
@@ -902,14 +902,15 @@ __global__ __launch_bounds__(256) void k_gather_matrix(int64_t nnzb, const int64
     double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, a2 = {0.0, 0.0}, a3 = {0.0, 0.0};
     int64_t k = k0;
     for (; k + 3 < k1; k += 4) {
-        const int32_t i0 = c_idx[k], i1 = c_idx[k + 1], i2 = c_idx[k + 2], i3 = c_idx[k + 3];
+        const uint32_t i0 = (uint32_t)c_idx[k], i1 = (uint32_t)c_idx[k + 1], i2 = (uint32_t)c_idx[k + 2],
+                       i3 = (uint32_t)c_idx[k + 3];
         const double2 v0 = K2[(int64_t)i0 * 8 + e2], v1 = K2[(int64_t)i1 * 8 + e2];
         const double2 v2 = K2[(int64_t)i2 * 8 + e2], v3 = K2[(int64_t)i3 * 8 + e2];
         a0.x += v0.x; a0.y += v0.y; a1.x += v1.x; a1.y += v1.y;
         a2.x += v2.x; a2.y += v2.y; a3.x += v3.x; a3.y += v3.y;
     }
     for (; k < k1; ++k) {
-        const double2 v0 = K2[(int64_t)c_idx[k] * 8 + e2];
+        const double2 v0 = K2[(int64_t)(uint32_t)c_idx[k] * 8 + e2];
         a0.x += v0.x; a0.y += v0.y;
     }
     double vx = (a0.x + a1.x) + (a2.x + a3.x), vy = (a0.y + a1.y) + (a2.y + a3.y);
