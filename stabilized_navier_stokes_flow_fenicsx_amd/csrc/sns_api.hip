@@ -625,6 +625,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     return SNS_OK;
 }
 
+int get_vec(sns_ctx* h, size_t k, double** out);
 int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
     if (form != SNS_FORM_STOKES && form != SNS_FORM_NS) { set_error("bad form"); return SNS_E_ARG; }
     if (form == SNS_FORM_NS && !w) { set_error("NS form needs a state vector"); return SNS_E_ARG; }
@@ -661,8 +662,9 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         HIP_TRY(hipGetLastError());
         return SNS_OK;
     }
-    if (fast_residual && want_matrix) {
-        // scratch-free path: every BSR block (and every node residual) is computed by the lanes that own it
+    if (try_fused) {
+        // scratch-free path: every BSR block (and every node residual) is computed by the lanes that own it; a
+        // state that violates its Dirichlet data adds the lifting term in a third pass over the boundary tets
         const unsigned go = (unsigned)((h->n_od + 255) / 256);
         const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
         if (!h->opt.corrected_convection) {
@@ -675,6 +677,18 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
                                h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
             hipLaunchKernelGGL((k_fused_diag<SNS_FORM_NS, true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
                                h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
+        }
+        if (!fast_residual && F) {
+            double* dl = nullptr;
+            SNS_TRY(get_vec(h, 13, &dl));
+            const int64_t ndof = 4 * (int64_t)h->n;
+            hipLaunchKernelGGL(k_bc_defect, dim3(vec_grid(ndof)), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w, dl);
+            if (!h->opt.corrected_convection)
+                hipLaunchKernelGGL((k_fused_lift<false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                                   h->c_idx, h->tets, h->pts, w, h->bc_mask, dl, nu, F);
+            else
+                hipLaunchKernelGGL((k_fused_lift<true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                                   h->c_idx, h->tets, h->pts, w, h->bc_mask, dl, nu, F);
         }
         h->has_matrix = true;
         h->pc_ready = false;

@@ -25,6 +25,11 @@ __global__ void k_fused_diag(int32_t n_rows, const int32_t* diag, const int64_t*
                              const int32_t* tets, const double* pts, const double* w, const uint8_t* bc_mask,
                              const double* bc_val, double nu, double* vals, double* F);
 template <bool corrected>
+__global__ void k_fused_lift(int32_t n_rows, const int32_t* diag, const int64_t* c_ptr, const int32_t* c_idx,
+                             const int32_t* tets, const double* pts, const double* w, const uint8_t* bc_mask,
+                             const double* dl, double nu, double* F);
+__global__ void k_bc_defect(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, const double* w, double* dl);
+template <bool corrected>
 __global__ void k_residual_tet(int64_t n_tets, const int32_t* tets, const double* pts, const double* w, double nu,
                                double* Fe);
 __global__ void k_snap_bc(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, double rel_tol, double* w);

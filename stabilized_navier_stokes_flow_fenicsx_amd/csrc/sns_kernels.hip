@@ -758,6 +758,68 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
         F[dof] = bc_mask[dof] ? ((FORM == SNS_FORM_STOKES ? 0.0 : w[dof]) - bc_val[dof]) : rq;
     }
 }
+// Lifting term of a state that violates its Dirichlet data (:65): F_free += A0[:,B] (g - x_B), A0 = the unconstrained
+// Jacobian.  Same work split as k_fused_diag (4 lanes per node, DPP quad sums); only tets with a violated Dirichlet
+// dof (dl != 0 on one of their nodes) cost anything: their blocks (a,b) are recomputed and applied to dl_b.
+template <bool corrected>
+__global__ __launch_bounds__(256) void k_fused_lift(int32_t n_rows, const int32_t* __restrict__ diag,
+                                                    const int64_t* __restrict__ c_ptr,
+                                                    const int32_t* __restrict__ c_idx,
+                                                    const int32_t* __restrict__ tets, const double* __restrict__ pts,
+                                                    const double* __restrict__ w, const uint8_t* __restrict__ bc_mask,
+                                                    const double* __restrict__ dl, double nu, double* __restrict__ F) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t node = gid >> 2;
+    const int q = (int)(gid & 3);
+    const bool live = node < n_rows;
+    double R[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        const int64_t s = diag[node];
+        for (int64_t k = c_ptr[s] + q; k < c_ptr[s + 1]; k += 4) {
+            const uint32_t id = (uint32_t)c_idx[k];
+            const int a = (id >> 2) & 3;
+            const int4 tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
+            const int32_t nd[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) {
+                const double2* dp = reinterpret_cast<const double2*>(dl + 4 * (int64_t)nd[b]);
+                const double2 d01 = dp[0], d23 = dp[1];
+                if (d01.x == 0.0 && d01.y == 0.0 && d23.x == 0.0 && d23.y == 0.0) continue;
+                double blk[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) blk[e] = 0.0;
+                tet_block_accumulate<corrected>(tv, pts, w, nu, a, b, false, blk, nullptr);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    R[c] += blk[4 * c] * d01.x + blk[4 * c + 1] * d01.y + blk[4 * c + 2] * d23.x + blk[4 * c + 3] * d23.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double v = R[c];
+        v += quad_perm<0xB1>(v);
+        v += quad_perm<0x4E>(v);
+        R[c] = v;
+    }
+    if (!live) return;
+    const int64_t dof = 4 * node + q;
+    const double rq = q == 0 ? R[0] : (q == 1 ? R[1] : (q == 2 ? R[2] : R[3]));
+    if (!bc_mask[dof]) F[dof] += rq;
+}
+template __global__ void k_fused_lift<false>(int32_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*,
+                                             const double*, const double*, const uint8_t*, const double*, double, double*);
+template __global__ void k_fused_lift<true>(int32_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*,
+                                            const double*, const double*, const uint8_t*, const double*, double, double*);
+
+// dl = g - w on Dirichlet dofs, 0 elsewhere
+__global__ __launch_bounds__(256) void k_bc_defect(int64_t ndof, const uint8_t* __restrict__ bc_mask,
+                                                   const double* __restrict__ bc_val, const double* __restrict__ w,
+                                                   double* __restrict__ dl) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndof; i += (int64_t)gridDim.x * blockDim.x)
+        dl[i] = bc_mask[i] ? (bc_val[i] - w[i]) : 0.0;
+}
+
 #define SNS_INST_FUSED(FM, C)                                                                                      \
     template __global__ void k_fused_offdiag<FM, C>(int64_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
                                                 const int32_t*, const int32_t*, const double*, const double*,       \

@@ -667,6 +667,13 @@ def test_fast_residual_path_when_bcs_hold(gpu, corrected):
         assert abs(sysS[1][0] - sysS[0][0]).max() < 1e-13 * abs(Ao).max() and abs(sysS[1][0] - Ao).max() < 1e-12 * abs(Ao).max()
         assert rel(sysS[1][1], sysS[0][1]) < 1e-13
     w2 = w.copy(); w2[np.nonzero(Bm)[0][0]] += 0.3               # one violated dof -> general path with lifting
+    sysL = []
+    for fused in (0, 1):                                         # staged lifting vs scratch-free lifting pass
+        P.set_options(assembly_fused=fused)
+        Fl = P.zeros()
+        P.jacobian(_dev(w2), "ns", residual_out=Fl)
+        sysL.append((P.to_scipy(), Fl.cpu().numpy()))
+    assert abs(sysL[1][0] - sysL[0][0]).max() < 1e-13 * abs(sysL[0][0]).max() and rel(sysL[1][1], sysL[0][1]) < 1e-13
     if not corrected:
         assert rel(P.residual(_dev(w2), "ns").cpu().numpy(), asm.residual_ns(m.points, m.tets, w2, 17.0, mask, g)) < 1e-12
     P.close()
