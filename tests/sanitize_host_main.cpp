@@ -1,0 +1,42 @@
+#include <cstdio>
+#include <vector>
+#include <random>
+#include <algorithm>
+#include "sns_internal.h"
+namespace sns { void set_error(const std::string&) {} }
+using namespace sns;
+int main() {
+    // Kuhn box mesh nx x ny x nz
+    const int nx = 14, ny = 9, nz = 7;
+    const int sy = nz + 1, sx = (ny + 1) * (nz + 1), n = (nx + 1) * sx;
+    const int perm[6][3] = {{0,1,2},{0,2,1},{1,0,2},{1,2,0},{2,0,1},{2,1,0}};
+    std::vector<int32_t> tets;
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) {
+        const int base = i * sx + j * sy + k;
+        for (auto& p : perm) {
+            int off[3] = {0, 0, 0}; int v = base; tets.push_back(v);
+            for (int s = 0; s < 3; ++s) { off[p[s]] = 1; tets.push_back(base + off[0] * sx + off[1] * sy + off[2]); }
+        }
+    }
+    // shuffle local vertex order of some tets
+    std::mt19937 rng(3);
+    for (size_t t = 0; t < tets.size() / 4; t += 3) std::shuffle(tets.begin() + 4 * t, tets.begin() + 4 * t + 4, rng);
+    const int64_t E = (int64_t)tets.size() / 4;
+    HostPattern P; HostAssemblyMaps M;
+    build_pattern(n, E, tets.data(), P, M);
+    std::printf("n %d E %ld nnzb %ld c_idx %zu\n", n, (long)E, (long)P.nnzb, M.c_idx.size());
+    HostPattern cur = P; int32_t nown = n;
+    for (int l = 0; l < 6 && nown > 8; ++l) {
+        std::vector<int32_t> agg; int32_t nc = 0;
+        aggregate_nodes(cur, nown, 8, agg, nc);
+        HostAggregation A; build_coarse_from_agg(cur, nown, agg, nc, nc, A);
+        std::printf("level %d: %d -> %d nodes, coarse nnzb %ld, r_idx %zu\n", l, nown, nc, (long)A.coarse.nnzb, A.r_idx.size());
+        cur = A.coarse; nown = nc;
+    }
+    // partial-active aggregation (distributed level 0)
+    std::vector<int32_t> agg; int32_t nc = 0;
+    aggregate_nodes(P, n / 2, 8, agg, nc);
+    HostAggregation A2; build_aggregation_active(P, n / 2, 8, A2);
+    std::printf("active aggregation: %d aggregates\n", A2.nc);
+    return 0;
+}

@@ -283,3 +283,28 @@ def test_bench_helpers_without_gpu():
     assert t is not None and 2.0e9 < t < 3.0e9               # 2.14 GB algorithmic, ~2.4 GB measured
     assert bench.pmc_traffic("no_such_kernel") is None
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_host_symbolic_setup_under_sanitizers(tmp_path):
+    """The host-side setup code (BSR pattern, gather lists, aggregation, coarse patterns: sns_host.cpp) built with
+    AddressSanitizer + UBSan and run on a Kuhn box with shuffled cell-local vertex orders (GPU sanitizers are not
+    available on the pool, so the CPU build is where memory errors of the symbolic phase would show)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sanitize_host")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-I", os.path.join(root, "include"),
+                            "-I", os.path.join(root, "stabilized_navier_stokes_flow_fenicsx_amd", "csrc"),
+                            os.path.join(root, "tests", "sanitize_host_main.cpp"),
+                            os.path.join(root, "stabilized_navier_stokes_flow_fenicsx_amd", "csrc", "sns_host.cpp"), "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True,
+                         env=dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "active aggregation" in run.stdout and "ERROR" not in run.stderr
