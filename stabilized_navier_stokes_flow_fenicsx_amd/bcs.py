@@ -122,3 +122,21 @@ def two_stream_profiles(flowrate_ratio: float, inner_half_width: float = 0.25):
         return s * 1.5 * (1 - flowrate_ratio) / area_2
 
     return p1, p2
+
+
+def dfg_bcs(mesh: TetMesh, u_max: float = 0.45) -> DirichletSet:
+    """[inflow, walls, obstacle] of DFG_3D_Validation.py:100-141: inlet u_x = 16 u_max y z (H-y)(H-z) / H^4, no slip
+    on the channel walls and the pillar, NO pressure condition (the script defines one at the outlet but leaves it
+    out of the list it passes on, :141) -- the outlet is the natural boundary."""
+    t = mesh.meta["tags"]
+    H = mesh.meta["width"]
+
+    def inflow(x):
+        ux = u_max * (4 * x[:, 1] * (H - x[:, 1]) / H ** 2) * (4 * x[:, 2] * (H - x[:, 2]) / H ** 2)
+        return np.stack([ux, np.zeros(len(x)), np.zeros(len(x))], axis=1)
+
+    return DirichletSet(mesh, [
+        _vel_bc(mesh.facet_nodes(t["inlet"]), inflow, mesh.points),
+        _vel_bc(mesh.facet_nodes(t["wall"]), (0.0, 0.0, 0.0), mesh.points),
+        _vel_bc(mesh.facet_nodes(t["obstacle"]), (0.0, 0.0, 0.0), mesh.points),
+    ])

@@ -252,6 +252,77 @@ def delaunay_duct_mesh(n: int = 8, x_outlet: float = 2.0, *, seed: int = 0, min_
                    meta={"lo": lo, "hi": hi, "tags": tags, "kind": "duct"})
 
 
+DFG_TAGS = {"inlet": 2, "outlet": 3, "wall": 4, "obstacle": 5}   # DFG_3D_Validation.py:104-109
+
+
+def dfg_pillar_mesh(n: int = 32, *, seed: int = 0, length: float = 2.2, width: float = 0.41, radius: float = 0.05,
+                    centre=(0.5, 0.2), refine: float = 1.0) -> TetMesh:
+    """Channel [0,length] x [0,width]^2 with the circular pillar of dfg_pillar_3D.geo (r = 0.05 at (0.5, 0.2), axis
+    along z): gmsh is not available offline, so the mesh is a Delaunay tetrahedralisation (scipy) of a jittered
+    lattice with h = width/n, exact points on the box faces and rings of points on the pillar surface
+    (spacing h*refine); tets inside the pillar are removed.  Facet tags as in DFG_3D_Validation.py:104-109."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    h = width / n
+    nx = int(round(length / h))
+    xs, ys, zs = np.linspace(0, length, nx + 1), np.linspace(0, width, n + 1), np.linspace(0, width, n + 1)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    I, J, K = np.meshgrid(np.arange(nx + 1), np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    d = rng.uniform(-0.25, 0.25, size=pts.shape) * h
+    d[:, 0][((I == 0) | (I == nx)).ravel()] = 0.0
+    d[:, 1][((J == 0) | (J == n)).ravel()] = 0.0
+    d[:, 2][((K == 0) | (K == n)).ravel()] = 0.0
+    pts = pts + d
+    cx, cy = centre
+    rr = np.hypot(pts[:, 0] - cx, pts[:, 1] - cy)
+    pts = pts[rr > radius + 0.55 * h * refine]
+    # rings on the pillar surface (and one ring just outside it) on every z-plane of the lattice, staggered
+    nth = max(16, int(round(2 * np.pi * radius / (h * refine))))
+    rings = []
+    for k, z in enumerate(zs):
+        for rad, off in ((radius, 0.0), (radius + 0.6 * h * refine, 0.5)):
+            th = 2 * np.pi * (np.arange(nth) + 0.5 * (k % 2) + off) / nth
+            rings.append(np.stack([cx + rad * np.cos(th), cy + rad * np.sin(th), np.full(nth, z)], axis=1))
+    ring = np.concatenate(rings)
+    n_lat = len(pts)
+    pts = np.concatenate([pts, ring])
+    on_pillar = np.zeros(len(pts), dtype=bool)
+    on_pillar[n_lat:] = np.isclose(np.hypot(ring[:, 0] - cx, ring[:, 1] - cy), radius)
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    X4 = pts[tets]
+    vol = np.abs(np.linalg.det(np.stack([X4[:, 1] - X4[:, 0], X4[:, 2] - X4[:, 0], X4[:, 3] - X4[:, 0]], axis=2))) / 6.0
+    cen = X4.mean(axis=1)
+    inside = np.hypot(cen[:, 0] - cx, cen[:, 1] - cy) < radius * np.cos(np.pi / nth)
+    inside |= on_pillar[tets].all(axis=1)                   # chord slivers spanned by surface points only
+    tets = tets[(vol > 1e-9 * h ** 3) & ~inside].astype(np.int32)
+    used = np.unique(tets)
+    if len(used) != len(pts):                               # drop orphaned points, renumber
+        remap = -np.ones(len(pts), dtype=np.int64)
+        remap[used] = np.arange(len(used))
+        pts, on_pillar, tets = pts[used], on_pillar[used], remap[tets].astype(np.int32)
+    fac = _boundary_facets(tets)
+    lo, hi = (0.0, 0.0, 0.0), (float(length), float(width), float(width))
+    t = DFG_TAGS
+
+    def tagger(on, _cent):
+        tag = np.full(fac.shape[0], -1)
+        for k_ in ("ylo", "yhi", "zlo", "zhi"):
+            tag[on[k_]] = t["wall"]
+        tag[on["xlo"]] = t["inlet"]
+        tag[on["xhi"]] = t["outlet"]
+        return tag
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    pil = (ft < 0) & on_pillar[fac].all(axis=1)
+    ft[pil] = t["obstacle"]
+    if (ft < 0).any():
+        raise ValueError(f"dfg_pillar_mesh: {(ft < 0).sum()} boundary facets are neither on the box nor on the pillar")
+    return TetMesh(pts, tets, fac, ft.astype(np.int32), name="dfg-pillar",
+                   meta={"lo": lo, "hi": hi, "tags": dict(t), "kind": "dfg", "radius": radius, "centre": tuple(centre),
+                         "width": width, "length": length, "h": h})
+
+
 def cavity_mesh(n: int = 16, *, jitter: float = 0.0) -> TetMesh:
     """Unit-cube lid-driven cavity, lid at y=1 (LidDrivenNavierStokesFlow.py:33-43 in 3-D)."""
     tags = dict(CAVITY_TAGS)

@@ -577,6 +577,28 @@ def test_delaunay_unstructured_mesh(gpu, n, seed):
     P.close()
 
 
+def test_dfg_pillar_benchmark_drag_and_pressure_drop(gpu):
+    """External known answer for the whole chain (mesh -> G-metric P1-P1 discretisation -> AMG/Newton -> traction
+    functional): the pillar channel of Validation_Flow/DFG_3D_Validation.py (Re = 20; the 3D-1Z case of the DFG
+    benchmark, literature C_d 6.05-6.25, C_l 0.008-0.010, Delta p 0.165-0.175).  On Delaunay meshes of the geometry the
+    solver gives C_d 6.52 / 6.43 / 6.38 / 6.29 and Delta p 0.157 / 0.160 / 0.164 / 0.165 at h = W/32, W/40, W/50, W/64
+    (scripts/gpu_dfg3d.py); the coarsest of these runs here."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, functionals as Fn, mesh as M
+    nu = 0.001
+    m = M.reorder_for_locality(M.dfg_pillar_mesh(32))[0]
+    P = gpu(m, B.dfg_bcs(m), reynolds=1.0 / nu, ksp_max_it=3000)
+    U, r = P.stokes_solve()
+    w, res = P.newton_solve(U.clone())
+    assert r.reason > 0 and res.reason > 0 and res.its <= 6
+    wh = w.cpu().numpy()
+    cd, cl = Fn.drag_lift_coefficients(Fn.boundary_traction_force(m, wh, nu, m.meta["tags"]["obstacle"]))
+    W4 = wh.reshape(-1, 4)
+    near = lambda x, y, z: W4[np.argmin(((m.points - np.array([x, y, z])) ** 2).sum(axis=1)), 3]
+    dp = near(0.45, 0.2, 0.205) - near(0.55, 0.2, 0.205)
+    assert 6.2 < cd < 6.8 and 0.0 < cl < 0.03 and 0.145 < dp < 0.18, (cd, cl, dp)
+    P.close()
+
+
 def test_edge_cases_tiny_and_degenerate_inputs(gpu):
     """Smallest inputs: one tet, an isolated node (row with only a diagonal), zero Newton iterations when
     the guess already solves the problem, iteration caps reported with PETSc's negative reasons."""
