@@ -308,3 +308,25 @@ def test_host_symbolic_setup_under_sanitizers(tmp_path):
                          env=dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=0"))
     assert run.returncode == 0, run.stderr[-2000:]
     assert "active aggregation" in run.stdout and "ERROR" not in run.stderr
+
+
+def test_dfg_pillar_mesh_geometry():
+    """Delaunay mesh of the DFG pillar channel (dfg_pillar_3D.geo): watertight, fluid volume and pillar surface
+    area as the geometry says (the pillar is a polygonal prism: slightly larger volume, smaller area), tags and
+    boundary conditions of DFG_3D_Validation.py:100-141 (no pressure condition)."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.dfg_pillar_mesh(12)
+    X4 = m.points[m.tets]
+    vol = np.abs(np.linalg.det(np.stack([X4[:, 1] - X4[:, 0], X4[:, 2] - X4[:, 0], X4[:, 3] - X4[:, 0]], axis=2))).sum() / 6
+    exact = 2.2 * 0.41 * 0.41 - np.pi * 0.05 ** 2 * 0.41
+    assert exact < vol < exact * 1.001
+    t = m.meta["tags"]
+    Pf = m.points[m.facets[m.facet_tags == t["obstacle"]]]
+    area = 0.5 * np.linalg.norm(np.cross(Pf[:, 1] - Pf[:, 0], Pf[:, 2] - Pf[:, 0]), axis=1).sum()
+    assert 0.98 * 2 * np.pi * 0.05 * 0.41 < area < 2 * np.pi * 0.05 * 0.41
+    assert set(np.unique(m.facet_tags)) == {t["inlet"], t["outlet"], t["wall"], t["obstacle"]}
+    mask, g = B.dfg_bcs(m).flatten()
+    assert mask.reshape(-1, 4)[:, 3].sum() == 0                      # no pressure Dirichlet dofs
+    assert abs(g.max() - 0.45) < 5e-3 and g.min() == 0.0             # inlet peak u_max, no-slip elsewhere
+    on_pillar = m.facet_nodes(t["obstacle"])
+    assert np.allclose(np.hypot(m.points[on_pillar, 0] - 0.5, m.points[on_pillar, 1] - 0.2), 0.05)
