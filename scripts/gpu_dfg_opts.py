@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
-n = 32
+n = int(os.environ.get("DFG_N", "32"))
 m = M.reorder_for_locality(M.dfg_pillar_mesh(n))[0]
 bc = B.dfg_bcs(m)
 for spec in sys.argv[1:] or [""]:

@@ -35,6 +35,12 @@ from .interpolate import interpolate_initial_guess
 snes_ksp_type = "bicgstab"          # reference: 'tfqmr' (:77); both are short-recurrence Lanczos-type methods
 
 
+def _continuation() -> bool:
+    """SNS_CONTINUATION=1: retry a failed Newton solve with Reynolds-number continuation (the command lines stay
+    those of the reference scripts, so this is an environment switch)."""
+    return bool(os.environ.get("SNS_CONTINUATION"))
+
+
 def _rank():
     try:
         import torch.distributed as dist
@@ -238,7 +244,7 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     # Solve Coarse Navier Stokes
     if rank == 0:
         print("Interpolating Stokes Flow", flush=True)
-    w_coarse, u, p = solve_navier_stokes(P, U_stokes.clone(), rank)
+    w_coarse, u, p = solve_navier_stokes(P, U_stokes.clone(), rank, continuation=_continuation())
     w_coarse_host = _to_global_host(P, w_coarse)
     P.close()
     # Solve Navier Stokes With User Defined Mesh
@@ -247,7 +253,7 @@ def solve_NS_flow(argv=None, *, coarse_mesh_size: float = 0.1, device="cuda:0"):
     if rank == 0:
         print("Interpolating Coarse NS Flow", flush=True)
     w0 = interpolate_initial_guess(msh, w_coarse_host, msh_f)
-    w, u, p = solve_navier_stokes(Pf, _from_global_host(Pf, w0), rank)
+    w, u, p = solve_navier_stokes(Pf, _from_global_host(Pf, w0), rank, continuation=_continuation())
     wg = _to_global_host(Pf, w)
     out = dict(msh=msh_f, w=wg, u=wg.reshape(-1, 4)[:, :3].copy(), p=wg.reshape(-1, 4)[:, 3].copy(), Re=Re, img_fname=img_fname,
                channel_mesh_size=channel_mesh_size, flowrate_ratio=flowrate_ratio, newton=Pf.last_newton)
@@ -328,7 +334,7 @@ def lid_driven_main(argv=None):
     P = _problem(msh, B.cavity_bcs(msh), reynolds=float(Re))
     U, res = P.stokes_solve()
     print("Solved Stokes Flow")
-    w, u, p = solve_navier_stokes(P, U.clone(), _rank())
+    w, u, p = solve_navier_stokes(P, U.clone(), _rank(), continuation=_continuation())
     wg = _to_global_host(P, w)
     if _rank() == 0:
         print(f"run time = {time.time() - t0: 0.2f} sec")

@@ -384,16 +384,61 @@ def solve_stokes_problem(problem: FlowProblem, rank: int = 0):
     return U
 
 
-def solve_navier_stokes(problem: FlowProblem, w: torch.Tensor, rank: int = 0):
+def newton_with_reynolds_continuation(problem: FlowProblem, w: torch.Tensor, max_halvings: int = 6, verbose: bool = False):
+    """Newton at the problem's Reynolds number; if it fails (typically the first Jacobian at a guess far from the
+    solution, at a cell Reynolds number the preconditioner cannot handle), Re is halved until a solve converges and
+    then doubled back up, each stage starting from the previous solution.  NOT in the reference (which reports the
+    failed reason and carries on, :297-298): opt-in robustness.  Returns (w, result of the last stage)."""
+    Re = float(problem.options.reynolds)
+    w_try, res = problem.newton_solve(w.clone())
+    if res.reason > 0:
+        w.copy_(w_try)
+        return w, res
+    k = 0
+    cur = w.clone()
+    while True:                                         # go down until a stage converges from the given guess
+        k += 1
+        if k > max_halvings:
+            problem.set_options(reynolds=Re)
+            return w, res
+        problem.set_options(reynolds=Re / 2 ** k)
+        w_try, r = problem.newton_solve(cur.clone())
+        if verbose:
+            print(f"  continuation: Re {Re / 2 ** k:g}: SNES reason {r.reason}, {r.its} its, {r.ksp_its} ksp its", flush=True)
+        if r.reason > 0:
+            cur = w_try
+            break
+    total_ksp = res.ksp_its + r.ksp_its
+    while k > 0:                                        # ... and back up
+        k -= 1
+        problem.set_options(reynolds=Re / 2 ** k)
+        w_try, r = problem.newton_solve(cur.clone())
+        total_ksp += r.ksp_its
+        if verbose:
+            print(f"  continuation: Re {Re / 2 ** k:g}: SNES reason {r.reason}, {r.its} its, {r.ksp_its} ksp its", flush=True)
+        if r.reason <= 0:
+            problem.set_options(reynolds=Re)
+            return w, r
+        cur = w_try
+    w.copy_(cur)
+    r.ksp_its = total_ksp
+    return w, r
+
+
+def solve_navier_stokes(problem: FlowProblem, w: torch.Tensor, rank: int = 0, continuation: bool = False):
     """``solve_navier_stokes(a, w, dF, bcs, W, ksp_type, comm, rank)`` (:268-312).
 
     ``w`` is updated in place (``snes.solve(None, w)`` :293); returns
     ``(w, u, p)`` with u (n,3) and p (n,) the collapsed sub-functions (:310-312).
+    ``continuation=True`` (not in the reference) retries a failed solve with Reynolds-number continuation.
     """
     if rank == 0:
         print("Running SNES solver", flush=True)
         print("Start Nonlinear Solve", flush=True)
-    w, res = problem.newton_solve(w)
+    if continuation:
+        w, res = newton_with_reynolds_continuation(problem, w, verbose=(rank == 0))
+    else:
+        w, res = problem.newton_solve(w)
     if rank == 0:
         print(f"Num SNES iterations: {res.its}", flush=True)
         print(f"SNES termination reason: {res.reason}", flush=True)
