@@ -13,7 +13,7 @@ def beat():
 threading.Thread(target=beat, daemon=True).start()
 nu = 0.001
 for n in [int(a) for a in sys.argv[1:]] or [24]:
-    t0 = time.time(); m = M.dfg_pillar_mesh(n); m = M.reorder_for_locality(m)[0]; t1 = time.time()
+    t0 = time.time(); m = M.dfg_pillar_mesh(n, lattice=os.environ.get("DFG_LATTICE", "cubic")); m = M.reorder_for_locality(m)[0]; t1 = time.time()
     P = FlowProblem(m, B.dfg_bcs(m), reynolds=1.0 / nu, ksp_max_it=3000)
     U, r = P.stokes_solve()
     w, res = P.newton_solve(U.clone())

@@ -256,10 +256,10 @@ DFG_TAGS = {"inlet": 2, "outlet": 3, "wall": 4, "obstacle": 5}   # DFG_3D_Valida
 
 
 def dfg_pillar_mesh(n: int = 32, *, seed: int = 0, length: float = 2.2, width: float = 0.41, radius: float = 0.05,
-                    centre=(0.5, 0.2), refine: float = 1.0) -> TetMesh:
+                    centre=(0.5, 0.2), refine: float = 1.0, lattice: str = "bcc") -> TetMesh:
     """Channel [0,length] x [0,width]^2 with the circular pillar of dfg_pillar_3D.geo (r = 0.05 at (0.5, 0.2), axis
-    along z): gmsh is not available offline, so the mesh is a Delaunay tetrahedralisation (scipy) of a jittered
-    lattice with h = width/n, exact points on the box faces and rings of points on the pillar surface
+    along z): gmsh is not available offline, so the mesh is a Delaunay tetrahedralisation (scipy) of a slightly jittered
+    body-centred (``lattice="bcc"``, default: nearly regular tets) or cubic lattice with h = width/n, exact points on the box faces and rings of points on the pillar surface
     (spacing h*refine); tets inside the pillar are removed.  Facet tags as in DFG_3D_Validation.py:104-109."""
     from scipy.spatial import Delaunay
     rng = np.random.default_rng(seed)
@@ -273,7 +273,16 @@ def dfg_pillar_mesh(n: int = 32, *, seed: int = 0, length: float = 2.2, width: f
     d[:, 0][((I == 0) | (I == nx)).ravel()] = 0.0
     d[:, 1][((J == 0) | (J == n)).ravel()] = 0.0
     d[:, 2][((K == 0) | (K == n)).ravel()] = 0.0
-    pts = pts + d
+    if lattice == "bcc":
+        # body-centred lattice: cube centres added, jitter reduced -- its Delaunay tets are nearly regular in the
+        # interior (far fewer slivers than the perturbed cubic lattice)
+        d *= 0.2
+        Xc, Yc, Zc = np.meshgrid(0.5 * (xs[1:] + xs[:-1]), 0.5 * (ys[1:] + ys[:-1]), 0.5 * (zs[1:] + zs[:-1]), indexing="ij")
+        cen_pts = np.stack([Xc.ravel(), Yc.ravel(), Zc.ravel()], axis=1)
+        cen_pts = cen_pts + rng.uniform(-0.05, 0.05, size=cen_pts.shape) * h
+        pts = np.concatenate([pts + d, cen_pts])
+    else:
+        pts = pts + d
     cx, cy = centre
     rr = np.hypot(pts[:, 0] - cx, pts[:, 1] - cy)
     pts = pts[rr > radius + 0.55 * h * refine]

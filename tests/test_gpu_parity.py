@@ -580,9 +580,9 @@ def test_delaunay_unstructured_mesh(gpu, n, seed):
 def test_dfg_pillar_benchmark_drag_and_pressure_drop(gpu):
     """External known answer for the whole chain (mesh -> G-metric P1-P1 discretisation -> AMG/Newton -> traction
     functional): the pillar channel of Validation_Flow/DFG_3D_Validation.py (Re = 20; the 3D-1Z case of the DFG
-    benchmark, literature C_d 6.05-6.25, C_l 0.008-0.010, Delta p 0.165-0.175).  On Delaunay meshes of the geometry the
-    solver gives C_d 6.52 / 6.43 / 6.38 / 6.29 and Delta p 0.157 / 0.160 / 0.164 / 0.165 at h = W/32, W/40, W/50, W/64
-    (scripts/gpu_dfg3d.py); the coarsest of these runs here."""
+    benchmark, literature C_d 6.05-6.25 (6.185), C_l 0.008-0.010, Delta p 0.165-0.175).  On body-centred-lattice Delaunay
+    meshes of the geometry the solver gives C_d 6.318 / 6.262 / 6.236 / 6.196 and Delta p 0.161 / 0.160 / 0.163 / 0.166 at
+    h = W/32, W/40, W/50, W/64 (2.1 ... 16.7 M tets, scripts/gpu_dfg3d.py); the coarsest of these runs here."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, functionals as Fn, mesh as M
     nu = 0.001
     m = M.reorder_for_locality(M.dfg_pillar_mesh(32))[0]
@@ -595,7 +595,7 @@ def test_dfg_pillar_benchmark_drag_and_pressure_drop(gpu):
     W4 = wh.reshape(-1, 4)
     near = lambda x, y, z: W4[np.argmin(((m.points - np.array([x, y, z])) ** 2).sum(axis=1)), 3]
     dp = near(0.45, 0.2, 0.205) - near(0.55, 0.2, 0.205)
-    assert 6.2 < cd < 6.8 and 0.0 < cl < 0.03 and 0.145 < dp < 0.18, (cd, cl, dp)
+    assert 6.15 < cd < 6.5 and abs(cl) < 0.05 and 0.15 < dp < 0.175, (cd, cl, dp)
     P.close()
 
 
