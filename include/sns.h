@@ -111,6 +111,10 @@ typedef struct {
                                global block-Jacobi sweep */
     int    assembly_fused;  /* 1: scratch-free Jacobian assembly (each BSR block recomputed by its owner lane) when the
                                state satisfies the Dirichlet data; 0: always the staged element kernel + gather */
+    double stokes_viscosity; /* 2-D handles only: viscosity of the Stokes form (1.0: DFG_2D_Validation.py:107-110;
+                               nu = 1/Re: LidDrivenNavierStokesFlow.py:96-104) */
+    double stokes_beta;     /* 2-D handles only: mu_T = stokes_beta * h^2 (0.2: DFG_2D_Validation.py:104-106;
+                               a0/(4 nu), a0 = 1/3: LidDrivenNavierStokesFlow.py:98-100) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
@@ -128,6 +132,17 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets,
                const double* points_host, const int32_t* tets_host,
                const uint8_t* bc_mask_host, const double* bc_val_host,
                int device, const sns_options* opt);
+/* 2-D variant (triangles, LidDrivenFlow/LidDrivenNavierStokesFlow.py:29-30 create_rectangle, Validation_Flow/
+ * DFG_2D_Validation.py:28 read_from_msh(gdim=2)): points_host [n_nodes*2], tris_host [n_tris*3].  The handle keeps
+ * the node-blocked layout of 4 dofs per node [ux, uy, uz, p]; uz is constrained to 0 by the library (identity rows),
+ * bc_mask / bc_val still have 4*n_nodes entries.  On such a handle SNS_FORM_STOKES is the pressure-stabilised Stokes
+ * form with (stokes_viscosity, stokes_beta) and SNS_FORM_NS the P1-P1 form with the h-based Tezduyar UGN
+ * tau_SUPG / tau_LSIC (LidDrivenNavierStokesFlow.py:123-143 == DFG_2D_Validation.py:141-163) and its exact Gateaux
+ * derivative; every other entry point works unchanged.  Single GPU only (no sns_attach_comm).                    */
+int sns_create_2d(sns_handle* out, int32_t n_nodes, int64_t n_tris,
+                  const double* points_host, const int32_t* tris_host,
+                  const uint8_t* bc_mask_host, const double* bc_val_host,
+                  int device, const sns_options* opt);
 int sns_destroy(sns_handle h);
 int sns_set_stream(sns_handle h, void* hip_stream);
 int sns_set_options(sns_handle h, const sns_options* opt);

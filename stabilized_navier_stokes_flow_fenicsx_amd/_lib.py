@@ -31,6 +31,7 @@ class SnsOptions(C.Structure):
         ("snes_stol", C.c_double), ("snes_max_it", C.c_int), ("amg_max_levels", C.c_int),
         ("amg_coarse_size", C.c_int), ("amg_agg_size", C.c_int), ("amg_nu", C.c_int),
         ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int), ("amg_f32_matrix", C.c_int), ("amg_nu_coarse", C.c_int), ("amg_nu_deep", C.c_int), ("amg_nu_l2", C.c_int), ("amg_sweep_exchange_rows", C.c_int), ("amg_replicate_rows", C.c_int), ("amg_post_exchange", C.c_int), ("assembly_fused", C.c_int),
+        ("stokes_viscosity", C.c_double), ("stokes_beta", C.c_double),
     ]
 
 
@@ -56,6 +57,7 @@ _SIGNATURES = [
     ("sns_last_error", C.c_char_p, []),
     ("sns_version", C.c_char_p, []),
     ("sns_create", C.c_int, [C.POINTER(_H), C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int, C.POINTER(SnsOptions)]),
+    ("sns_create_2d", C.c_int, [C.POINTER(_H), C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int, C.POINTER(SnsOptions)]),
     ("sns_destroy", C.c_int, [_H]),
     ("sns_set_stream", C.c_int, [_H, _P]),
     ("sns_set_options", C.c_int, [_H, C.POINTER(SnsOptions)]),

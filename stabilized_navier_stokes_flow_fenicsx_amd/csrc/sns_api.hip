@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <string>
 #include <vector>
@@ -68,7 +69,8 @@ struct sns_ctx {
     sns_options opt;
     int device = 0;
     hipStream_t stream = nullptr;
-    // mesh
+    // mesh (dim 3: tets; dim 2: triangles in a stride-4 connectivity, z component a Dirichlet dof)
+    int dim = 3;
     int32_t n = 0, n_owned = 0;
     int64_t E = 0;
     int32_t* tets = nullptr;
@@ -82,8 +84,10 @@ struct sns_ctx {
     double* gext = nullptr;            // Dirichlet data extended by zero (the state the Stokes lifting term is taken at)
     int64_t n_od = 0;
     double *Ke = nullptr, *Fe = nullptr;
-    // operator hierarchy; levels[0] is the assembled fine operator
-    std::vector<Level> levels;
+    // operator hierarchy; levels[0] is the assembled fine operator.  A deque: references to a level stay valid
+    // while coarser levels are appended (a vector reallocation under a live Level& once handed a kernel dangling
+    // pointers)
+    std::deque<Level> levels;
     std::vector<int32_t*> slot_row;              // per level
     std::vector<uint8_t*> empty_c;               // per level (coarse side), level l -> empty flags of level l+1
     std::vector<double*> pong;                   // per level smoother ping-pong buffer
@@ -473,13 +477,6 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     const bool dist = c && c->active() && c->nranks > 1;
     HostPattern cur = fine;
     int32_t n_owned = h->n_owned;
-    // levels/side arrays must not reallocate while references into them are alive
-    const size_t cap = (size_t)std::max(2, o.amg_max_levels) + 2;
-    h->levels.reserve(cap);
-    h->slot_row.reserve(cap);
-    h->empty_c.reserve(cap);
-    h->pong.reserve(cap);
-    if (dist) c->plans.reserve(cap);
     h->ghost_gid.assign(1, {});
     h->ghost_own.assign(1, {});
     const int per_rank_coarse = dist ? std::max(1, o.amg_coarse_size / c->nranks) : o.amg_coarse_size;
@@ -626,9 +623,81 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
 }
 
 int get_vec(sns_ctx* h, size_t k, double** out);
+
+// 2-D handles (sns_create_2d): triangle P1-P1, Stokes with (stokes_viscosity, stokes_beta) and the UGN-stabilised
+// NS form of LidDrivenNavierStokesFlow.py:123-143 / DFG_2D_Validation.py:141-163.  Always the scratch-free path:
+// every BSR block by its owner lane, residual-only evaluations by one lane per triangle + the node gather.
+int assemble2d(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
+    Level& L = h->levels[0];
+    const unsigned go = (unsigned)((h->n_od + 255) / 256);
+    const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
+    const int64_t ndof = 4 * (int64_t)h->n;
+    const int gv = vec_grid(ndof);
+    if (h->E == 0) { set_error("empty mesh"); return SNS_E_ARG; }
+    if (form == SNS_FORM_STOKES) {
+        const double nu_s = h->opt.stokes_viscosity, beta = h->opt.stokes_beta;
+        const double* state = h->gext;            // w == NULL: the system of LinearProblem(a, L, bcs), F(0) = lifting
+        if (w) {                                  // linear residual at w: state = w with the Dirichlet data imposed
+            double* tmp = nullptr;
+            SNS_TRY(get_vec(h, 13, &tmp));
+            HIP_TRY(hipMemcpyAsync(tmp, w, ndof * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_snap_bc, dim3(gv), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, 1e300, tmp);
+            state = tmp;
+        }
+        if (want_matrix)
+            hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_STOKES_2D, false>), dim3(go), dim3(256), 0, h->stream, h->n_od,
+                               h->od_order, h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->tets, h->pts, state,
+                               h->bc_mask, nu_s, beta, L.vals);
+        if (want_matrix || F)
+            hipLaunchKernelGGL((k_fused_diag<SNS_FORM_STOKES_2D, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned,
+                               L.diag, h->c_ptr, h->c_idx, h->tets, h->pts, state, h->bc_mask, h->bc_val, nu_s, beta,
+                               want_matrix ? L.vals : (double*)nullptr, F);
+        if (w && F) hipLaunchKernelGGL(k_bc_residual, dim3(gv), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w, F);
+    } else {
+        const double nu = 1.0 / h->opt.reynolds;
+        bool lifted = false;
+        if (F) {
+            hipLaunchKernelGGL(k_count_bc_violations, dim3(gv), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w,
+                               h->partial);
+            reduce_local(h, gv, 1, h->d_scal + 60);
+            double nviol = 1.0;
+            SNS_TRY(fetch(h, h->d_scal + 60, 1, &nviol));
+            lifted = nviol != 0.0;
+        }
+        if (want_matrix) {
+            hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_UGN_2D, false>), dim3(go), dim3(256), 0, h->stream, h->n_od,
+                               h->od_order, h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask,
+                               nu, 0.0, L.vals);
+            hipLaunchKernelGGL((k_fused_diag<SNS_FORM_UGN_2D, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned,
+                               L.diag, h->c_ptr, h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, 0.0, L.vals, F);
+        } else {
+            if (!h->Fe) SNS_TRY(dev_alloc(&h->Fe, (size_t)h->E * 16));
+            hipLaunchKernelGGL(k_residual_tri, dim3((unsigned)((h->E + 255) / 256)), dim3(256), 0, h->stream, h->E,
+                               h->tets, h->pts, w, nu, h->Fe);
+            hipLaunchKernelGGL(k_gather_residual, dim3(gd), dim3(256), 0, h->stream, h->n_owned, h->nt_ptr, h->nt_idx,
+                               h->bc_mask, h->bc_val, w, h->Fe, F);
+        }
+        if (lifted && F) {                       // F += A0[:,B] (g - x_B)   (apply_lifting)
+            double* dl = nullptr;
+            SNS_TRY(get_vec(h, 13, &dl));
+            hipLaunchKernelGGL(k_bc_defect, dim3(gv), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w, dl);
+            hipLaunchKernelGGL((k_fused_lift<SNS_FORM_UGN_2D, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned,
+                               L.diag, h->c_ptr, h->c_idx, h->tets, h->pts, w, h->bc_mask, dl, nu, F);
+        }
+    }
+    if (want_matrix) {
+        h->has_matrix = true;
+        h->pc_ready = false;
+        h->matrix_form = form;
+    }
+    HIP_TRY(hipGetLastError());
+    return SNS_OK;
+}
+
 int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix) {
     if (form != SNS_FORM_STOKES && form != SNS_FORM_NS) { set_error("bad form"); return SNS_E_ARG; }
     if (form == SNS_FORM_NS && !w) { set_error("NS form needs a state vector"); return SNS_E_ARG; }
+    if (h->dim == 2) return assemble2d(h, form, w, F, want_matrix);
     const int grid = (int)((h->E + EL_TETS_PER_BLOCK - 1) / EL_TETS_PER_BLOCK);
     const double nu = 1.0 / h->opt.reynolds;
     bool fast_residual = false;
@@ -653,9 +722,9 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
         hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_STOKES, false>), dim3(go), dim3(256), 0, h->stream, h->n_od,
                            h->od_order, h->c_ptr, h->c_idx, h->slot_row[0], L.colind, h->tets, h->pts, h->gext,
-                           h->bc_mask, nu, L.vals);
+                           h->bc_mask, nu, 0.0, L.vals);
         hipLaunchKernelGGL((k_fused_diag<SNS_FORM_STOKES, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag,
-                           h->c_ptr, h->c_idx, h->tets, h->pts, h->gext, h->bc_mask, h->bc_val, nu, L.vals, F);
+                           h->c_ptr, h->c_idx, h->tets, h->pts, h->gext, h->bc_mask, h->bc_val, nu, 0.0, L.vals, F);
         h->has_matrix = true;
         h->pc_ready = false;
         h->matrix_form = form;
@@ -669,14 +738,14 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         const unsigned gd = (unsigned)((4 * (int64_t)h->n_owned + 255) / 256);
         if (!h->opt.corrected_convection) {
             hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_NS, false>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
-                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
+                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, 0.0, L.vals);
             hipLaunchKernelGGL((k_fused_diag<SNS_FORM_NS, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
-                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
+                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, 0.0, L.vals, F);
         } else {
             hipLaunchKernelGGL((k_fused_offdiag<SNS_FORM_NS, true>), dim3(go), dim3(256), 0, h->stream, h->n_od, h->od_order, h->c_ptr, h->c_idx,
-                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, L.vals);
+                               h->slot_row[0], L.colind, h->tets, h->pts, w, h->bc_mask, nu, 0.0, L.vals);
             hipLaunchKernelGGL((k_fused_diag<SNS_FORM_NS, true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
-                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, L.vals, F);
+                               h->c_idx, h->tets, h->pts, w, h->bc_mask, h->bc_val, nu, 0.0, L.vals, F);
         }
         if (!fast_residual && F) {
             double* dl = nullptr;
@@ -684,10 +753,10 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
             const int64_t ndof = 4 * (int64_t)h->n;
             hipLaunchKernelGGL(k_bc_defect, dim3(vec_grid(ndof)), dim3(256), 0, h->stream, ndof, h->bc_mask, h->bc_val, w, dl);
             if (!h->opt.corrected_convection)
-                hipLaunchKernelGGL((k_fused_lift<false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                hipLaunchKernelGGL((k_fused_lift<SNS_FORM_NS, false>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
                                    h->c_idx, h->tets, h->pts, w, h->bc_mask, dl, nu, F);
             else
-                hipLaunchKernelGGL((k_fused_lift<true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
+                hipLaunchKernelGGL((k_fused_lift<SNS_FORM_NS, true>), dim3(gd), dim3(256), 0, h->stream, h->n_owned, L.diag, h->c_ptr,
                                    h->c_idx, h->tets, h->pts, w, h->bc_mask, dl, nu, F);
         }
         h->has_matrix = true;
@@ -1500,43 +1569,72 @@ void sns_default_options(sns_options* o) {
     o->amg_sweep_exchange_rows = 0;
     o->amg_replicate_rows = 65536;
     o->amg_post_exchange = 1;
+    o->stokes_viscosity = 1.0;
+    o->stokes_beta = 0.2;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
 const char* sns_version(void) { return "sns 0.1 (gfx950)"; }
 
-int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* points, const int32_t* tets,
-               const uint8_t* bc_mask, const double* bc_val, int device, const sns_options* opt) {
-    if (!out || n_nodes <= 0 || n_tets < 0 || !points || !tets || !bc_mask || !bc_val) {
+// dim 3: points [n*3], cells [E*4];  dim 2: points [n*2], cells [E*3]
+static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* points_in,
+                         const int32_t* cells_in, const uint8_t* bc_mask_in, const double* bc_val_in, int device,
+                         const sns_options* opt) {
+    if (!out || n_nodes <= 0 || n_tets < 0 || !points_in || !cells_in || !bc_mask_in || !bc_val_in) {
         set_error("sns_create: null or empty input");
         return SNS_E_ARG;
     }
     *out = nullptr;
-    // host validation: vertex ids in range, non-degenerate tets (kernels divide by det J)
+    const int npe = dim + 1;
+    // host validation: vertex ids in range, non-degenerate cells (kernels divide by det J)
     for (int64_t t = 0; t < n_tets; ++t) {
-        const int32_t* v = tets + 4 * t;
-        for (int a = 0; a < 4; ++a)
-            if (v[a] < 0 || v[a] >= n_nodes) { set_error("tet vertex id out of range"); return SNS_E_MESH; }
-        const double* x0 = points + 3 * (int64_t)v[0];
-        double J[3][3];
-        for (int c = 0; c < 3; ++c)
-            for (int i = 0; i < 3; ++i) J[i][c] = points[3 * (int64_t)v[c + 1] + i] - x0[i];
+        const int32_t* v = cells_in + npe * t;
+        for (int a = 0; a < npe; ++a)
+            if (v[a] < 0 || v[a] >= n_nodes) { set_error("cell vertex id out of range"); return SNS_E_MESH; }
+        const double* x0 = points_in + dim * (int64_t)v[0];
+        double J[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int c = 0; c < dim; ++c)
+            for (int i = 0; i < dim; ++i) J[i][c] = points_in[dim * (int64_t)v[c + 1] + i] - x0[i];
         const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) -
                            J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
                            J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-        if (!(std::fabs(det) > 0.0)) { set_error("degenerate tet " + std::to_string(t)); return SNS_E_MESH; }
+        if (!(std::fabs(det) > 0.0)) { set_error("degenerate cell " + std::to_string(t)); return SNS_E_MESH; }
+    }
+    // device layout is the 3-D one in both cases: points in a stride of 3, cells in a stride of 4 (a triangle repeats
+    // its last vertex), 4 dofs per node; a 2-D handle constrains the unused z component to 0
+    std::vector<double> pts3;
+    std::vector<int32_t> cells4;
+    std::vector<uint8_t> mask2;
+    std::vector<double> val2;
+    const double* points = points_in;
+    const int32_t* tets = cells_in;
+    const uint8_t* bc_mask = bc_mask_in;
+    const double* bc_val = bc_val_in;
+    if (dim == 2) {
+        pts3.assign((size_t)3 * n_nodes, 0.0);
+        for (int32_t i = 0; i < n_nodes; ++i) { pts3[3 * (size_t)i] = points_in[2 * (size_t)i]; pts3[3 * (size_t)i + 1] = points_in[2 * (size_t)i + 1]; }
+        cells4.resize((size_t)4 * n_tets);
+        for (int64_t t = 0; t < n_tets; ++t) {
+            for (int a = 0; a < 3; ++a) cells4[4 * (size_t)t + a] = cells_in[3 * t + a];
+            cells4[4 * (size_t)t + 3] = cells_in[3 * t + 2];
+        }
+        mask2.assign(bc_mask_in, bc_mask_in + (size_t)4 * n_nodes);
+        val2.assign(bc_val_in, bc_val_in + (size_t)4 * n_nodes);
+        for (int32_t i = 0; i < n_nodes; ++i) { mask2[4 * (size_t)i + 2] = 1; val2[4 * (size_t)i + 2] = 0.0; }
+        points = pts3.data(); tets = cells4.data(); bc_mask = mask2.data(); bc_val = val2.data();
     }
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<sns_ctx> h(new sns_ctx);
     if (opt) h->opt = *opt; else sns_default_options(&h->opt);
     h->device = device;
+    h->dim = dim;
     h->n = n_nodes;
     h->n_owned = n_nodes;
     h->E = n_tets;
     HostPattern P;
     HostAssemblyMaps M;
     try {
-        build_pattern(n_nodes, n_tets, tets, P, M);
+        build_pattern(n_nodes, n_tets, tets, P, M, npe);
     } catch (const std::exception& e) {
         set_error(e.what());
         return SNS_E_MESH;
@@ -1584,10 +1682,6 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
         h->n_od = (int64_t)order.size();
         SNS_TRY(dev_upload(&h->od_order, order, nullptr));
     }
-    h->levels.reserve(64);
-    h->slot_row.reserve(64);
-    h->empty_c.reserve(64);
-    h->pong.reserve(64);
     h->levels.emplace_back();
     h->slot_row.push_back(nullptr);
     h->empty_c.push_back(nullptr);
@@ -1618,6 +1712,15 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* p
     h->pattern.reset(new HostPattern(std::move(P)));
     *out = h.release();
     return SNS_OK;
+}
+
+int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* points, const int32_t* tets,
+               const uint8_t* bc_mask, const double* bc_val, int device, const sns_options* opt) {
+    return create_common(3, out, n_nodes, n_tets, points, tets, bc_mask, bc_val, device, opt);
+}
+int sns_create_2d(sns_handle* out, int32_t n_nodes, int64_t n_tris, const double* points, const int32_t* tris,
+                  const uint8_t* bc_mask, const double* bc_val, int device, const sns_options* opt) {
+    return create_common(2, out, n_nodes, n_tris, points, tris, bc_mask, bc_val, device, opt);
 }
 
 }  // extern "C"
@@ -1742,7 +1845,6 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     }   // uid == NULL and no team: local part only, the caller moves ghost values and reduces (tests)
     h->n_owned = n_owned;
     h->levels[0].n_owned = n_owned;
-    c.plans.reserve(64);
     c.plans.emplace_back();
     Plan& p = c.plans[0];
     p.nbr.assign(nbr, nbr + n_nbr);

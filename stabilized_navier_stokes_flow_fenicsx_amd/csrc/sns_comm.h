@@ -14,6 +14,7 @@
 
 #include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,7 +48,7 @@ struct Comm {
     ncclComm_t nccl = nullptr;
     Team* team = nullptr;
     int rank = 0, nranks = 1;
-    std::vector<Plan> plans;                     // per hierarchy level; plans[0] = assembled operator
+    std::deque<Plan> plans;                      // per hierarchy level; plans[0] = assembled operator (stable references)
     bool active() const { return nccl != nullptr || team != nullptr; }
 };
 

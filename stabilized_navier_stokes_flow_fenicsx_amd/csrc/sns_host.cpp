@@ -15,23 +15,25 @@
 
 namespace sns {
 
-void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, HostAssemblyMaps& M) {
+// npe = vertices per cell (4: tets, 3: triangles); the connectivity is stored in a stride of 4 either way and
+// element-block ids stay cell*16 + a*4 + b.
+void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, HostAssemblyMaps& M, int npe) {
     // element-block ids tet*16 + a*4 + b are stored as UNSIGNED 32-bit values: up to 2^28 = 268 M tets
     if (E * 16 > (int64_t)UINT32_MAX) throw std::runtime_error("mesh too large for 32-bit element-block ids (268 M tets)");
     // ---- node -> incident (tet, a) ------------------------------------------
     M.nt_ptr.assign((size_t)n + 1, 0);
     for (int64_t t = 0; t < E; ++t)
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < npe; ++a) {
             int32_t v = tets[4 * t + a];
             if (v < 0 || v >= n) throw std::runtime_error("tet vertex id out of range");
             M.nt_ptr[(size_t)v + 1]++;
         }
     for (int32_t i = 0; i < n; ++i) M.nt_ptr[i + 1] += M.nt_ptr[i];
-    M.nt_idx.resize((size_t)4 * E);
+    M.nt_idx.resize((size_t)npe * E);
     {
         std::vector<int64_t> cur(M.nt_ptr.begin(), M.nt_ptr.end() - 1);
         for (int64_t t = 0; t < E; ++t)                       // tet order => deterministic gather order
-            for (int a = 0; a < 4; ++a) M.nt_idx[(size_t)cur[tets[4 * t + a]]++] = (int32_t)(4 * t + a);
+            for (int a = 0; a < npe; ++a) M.nt_idx[(size_t)cur[tets[4 * t + a]]++] = (int32_t)(4 * t + a);
     }
     // ---- rows: sorted unique neighbour nodes ----------------------------------
     P.n = n;
@@ -45,7 +47,7 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
             tmp.clear();
             for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
                 const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
-                tmp.insert(tmp.end(), tv, tv + 4);
+                tmp.insert(tmp.end(), tv, tv + npe);
             }
             if (tmp.empty()) tmp.push_back(i);                // isolated node: keep a diagonal
             std::sort(tmp.begin(), tmp.end());
@@ -67,7 +69,7 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
             tmp.clear();
             for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
                 const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
-                tmp.insert(tmp.end(), tv, tv + 4);
+                tmp.insert(tmp.end(), tv, tv + npe);
             }
             if (tmp.empty()) tmp.push_back(i);
             std::sort(tmp.begin(), tmp.end());
@@ -86,14 +88,14 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
         const int32_t len = P.rowptr[i + 1] - P.rowptr[i];
         for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
             const int32_t* tv = tets + 4 * (int64_t)(M.nt_idx[k] >> 2);
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < npe; ++b) {
                 int32_t s = P.rowptr[i] + (int32_t)(std::lower_bound(cb, cb + len, tv[b]) - cb);
                 M.c_ptr[(size_t)s + 1]++;
             }
         }
     }
     for (int64_t s = 0; s < nnzb; ++s) M.c_ptr[s + 1] += M.c_ptr[s];
-    M.c_idx.resize((size_t)16 * E);
+    M.c_idx.resize((size_t)npe * npe * E);
 #pragma omp parallel
     {
         std::vector<int32_t> fill;
@@ -105,7 +107,7 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
             for (int64_t k = M.nt_ptr[i]; k < M.nt_ptr[i + 1]; ++k) {
                 const int32_t ta = M.nt_idx[k];
                 const int32_t* tv = tets + 4 * (int64_t)(ta >> 2);
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < npe; ++b) {
                     int32_t j = (int32_t)(std::lower_bound(cb, cb + len, tv[b]) - cb);
                     int64_t s = P.rowptr[i] + j;
                     M.c_idx[(size_t)(M.c_ptr[s] + fill[j]++)] =
@@ -243,7 +245,7 @@ extern "C" int sns_host_pattern(int32_t n, int64_t E, const int32_t* tets, int64
     sns::HostPattern P;
     sns::HostAssemblyMaps M;
     try {
-        sns::build_pattern(n, E, tets, P, M);
+        sns::build_pattern(n, E, tets, P, M, 4);
     } catch (const std::exception& e) {
         sns::set_error(e.what());
         return SNS_E_MESH;

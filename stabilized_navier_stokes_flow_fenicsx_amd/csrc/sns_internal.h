@@ -36,7 +36,7 @@ struct HostAggregation {
 };
 
 void build_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets, HostPattern& P,
-                   HostAssemblyMaps& M);
+                   HostAssemblyMaps& M, int npe = 4);
 void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A);
 // same, but only nodes [0, n_active) take part (distributed level 0: owned nodes only)
 void build_aggregation_active(const HostPattern& fine, int32_t n_active, int max_agg, HostAggregation& A);

@@ -10,6 +10,11 @@ namespace sns {
 
 constexpr int EL_TETS_PER_BLOCK = 16;   // tets per 256-thread workgroup of k_element
 
+// internal form ids of the 2-D handles (the public API keeps SNS_FORM_STOKES / SNS_FORM_NS; sns_create_2d handles
+// map them to these)
+#define SNS_FORM_STOKES_2D 2
+#define SNS_FORM_UGN_2D 3
+
 enum SpmvMode { SPMV_AX = 0, SPMV_B_MINUS_AX = 1, SPMV_JACOBI = 2, SPMV_AX_DOT = 3 };
 
 template <int FORM, bool corrected>
@@ -19,12 +24,12 @@ __global__ void k_element(int64_t n_tets, const int32_t* tets, const double* pts
 template <int FORM, bool corrected>
 __global__ void k_fused_offdiag(int64_t n_od, const int32_t* od_order, const int64_t* c_ptr, const int32_t* c_idx, const int32_t* slot_row,
                                 const int32_t* colind, const int32_t* tets, const double* pts, const double* w,
-                                const uint8_t* bc_mask, double nu, double* vals);
+                                const uint8_t* bc_mask, double nu, double aux, double* vals);
 template <int FORM, bool corrected>
 __global__ void k_fused_diag(int32_t n_rows, const int32_t* diag, const int64_t* c_ptr, const int32_t* c_idx,
                              const int32_t* tets, const double* pts, const double* w, const uint8_t* bc_mask,
-                             const double* bc_val, double nu, double* vals, double* F);
-template <bool corrected>
+                             const double* bc_val, double nu, double aux, double* vals, double* F);
+template <int FORM, bool corrected>
 __global__ void k_fused_lift(int32_t n_rows, const int32_t* diag, const int64_t* c_ptr, const int32_t* c_idx,
                              const int32_t* tets, const double* pts, const double* w, const uint8_t* bc_mask,
                              const double* dl, double nu, double* F);
@@ -32,6 +37,9 @@ __global__ void k_bc_defect(int64_t ndof, const uint8_t* bc_mask, const double* 
 template <bool corrected>
 __global__ void k_residual_tet(int64_t n_tets, const int32_t* tets, const double* pts, const double* w, double nu,
                                double* Fe);
+__global__ void k_residual_tri(int64_t n_tris, const int32_t* tets, const double* pts, const double* w, double nu,
+                               double* Fe);
+__global__ void k_bc_residual(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, const double* w, double* F);
 __global__ void k_snap_bc(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, double rel_tol, double* w);
 __global__ void k_count_bc_violations(int64_t ndof, const uint8_t* bc_mask, const double* bc_val, const double* w,
                                       double* partial);

@@ -633,6 +633,210 @@ __device__ __forceinline__ void tet_block_accumulate_stokes(const int4 tv, const
     }
 }
 
+// ============================================================================
+// 2-D triangle P1-P1 variants (handle created by sns_create_2d).  Same node-blocked layout [ux,uy,uz,p]
+// (uz is a homogeneous Dirichlet dof: identity row), tets[] holds 3 vertex ids per cell in a stride of 4.
+//   * Stokes   nu_s (grad u, grad v) - (p, div v) + (div u, q) + beta h^2 (grad p, grad q)
+//       DFG_2D_Validation.py:107-117 (nu_s = 1, beta = 0.2), LidDrivenNavierStokesFlow.py:96-109 (nu, 1/(12 nu))
+//   * NS with the h-based Tezduyar UGN parameters, LidDrivenNavierStokesFlow.py:123-143 ==
+//       DFG_2D_Validation.py:141-163:  tau_SUPG = (inv1 + (4 nu / h^2)^2)^-1/2, inv1 = |u| <= 1e-8 ? 0 : (2|u|/h)^2,
+//       tau_LSIC = h/2 |u| z, z = Re_UGN <= 3 ? Re_UGN/3 : 1, Re_UGN = |u| h / (2 nu); convection and SUPG test
+//       function are the consistent (u.grad)(.) there (dot(u, nabla_grad(.))), and the exact Gateaux derivative
+//       differentiates both taus (each branch of the conditionals separately, as ufl.derivative does).
+// dx(degree 2) on a triangle: 3-point rule (1/6,1/6), (1/6,2/3), (2/3,1/6), weights 1/6.
+// ============================================================================
+#define T13 0.33333333333333333
+#define T16 0.16666666666666666
+#define T23 0.66666666666666663
+
+// phi_v at quadrature point q: the vertex that carries 2/3 is 0, 2, 1 for q = 0, 1, 2
+__device__ __forceinline__ double phi_q2(int q, int v) { return v == ((3 - q) % 3) ? T23 : T16; }
+
+struct TriGeom {
+    double g[3][2];     // grad phi_v
+    double wd;          // |det J| / 6  (= quadrature weight x |det J|)
+    double h2;          // CellDiameter^2
+};
+__device__ __forceinline__ void tri_geometry(const int4 tv, const double* __restrict__ pts, TriGeom& T) {
+    const int32_t nd[3] = {tv.x, tv.y, tv.z};
+    double X[3][2];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const double* pp = pts + 3 * (int64_t)nd[v];
+        X[v][0] = pp[0]; X[v][1] = pp[1];
+    }
+    const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
+    const double J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
+    const double det = J00 * J11 - J01 * J10;
+    const double id = 1.0 / det;
+    // K = J^-1, K[k][j] = dX_k / dx_j ; grad phi_1 = K[0][:], grad phi_2 = K[1][:]
+    T.g[1][0] = J11 * id;  T.g[1][1] = -J01 * id;
+    T.g[2][0] = -J10 * id; T.g[2][1] = J00 * id;
+    T.g[0][0] = -(T.g[1][0] + T.g[2][0]);
+    T.g[0][1] = -(T.g[1][1] + T.g[2][1]);
+    T.wd = fabs(det) * T16;
+    double h2 = 0.0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int u = v + 1; u < 3; ++u) {
+            const double d0 = X[u][0] - X[v][0], d1 = X[u][1] - X[v][1];
+            h2 = fmax(h2, d0 * d0 + d1 * d1);
+        }
+    T.h2 = h2;
+}
+__device__ __forceinline__ void tri_state(const int4 tv, const double* __restrict__ w, double W[3][3]) {
+    const int32_t nd[3] = {tv.x, tv.y, tv.z};
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const double2* wp = reinterpret_cast<const double2*>(w + 4 * (int64_t)nd[v]);
+        const double2 w0 = wp[0], w1 = wp[1];
+        W[v][0] = w0.x; W[v][1] = w0.y; W[v][2] = w1.y;       // ux, uy, p
+    }
+}
+
+// per-point UGN scalars at velocity u (h, h2 of the cell): tau_SUPG, tau_LSIC and the coefficients c with
+// d tau = c_tau (u . du), d tau_LSIC = c_L (u . du)
+__device__ __forceinline__ void ugn_taus(const double u[2], double h, double h2, double nu, double& tau, double& ctau,
+                                         double& tauL, double& cL) {
+    const double uu = u[0] * u[0] + u[1] * u[1];
+    const double un = sqrt(uu);
+    const bool slow = un <= 1e-8;                                  // conditional(le(u_norm, 1e-8), 0, .)
+    const double c4 = 4.0 / h2;
+    const double i3 = 4.0 * nu / h2;                               // 1 / tau_SUNG3
+    const double m = (slow ? 0.0 : c4 * uu) + i3 * i3;
+    tau = rsqrt(m);
+    ctau = slow ? 0.0 : -tau * tau * tau * c4;
+    const double ReU = un * h / (2.0 * nu);
+    if (ReU <= 3.0) {                                              // z = Re_UGN / 3
+        tauL = 0.5 * h * un * (ReU * T13);
+        cL = h2 / (6.0 * nu);
+    } else {                                                       // z = 1
+        tauL = 0.5 * h * un;
+        cL = 0.5 * h / un;
+    }
+}
+
+__device__ __forceinline__ void tri_block_accumulate_ugn(const int4 tv, const double* __restrict__ pts,
+                                                         const double* __restrict__ w, double nu, int a, int b,
+                                                         bool want_res, double acc[16], double Ra[4]) {
+    TriGeom T;
+    tri_geometry(tv, pts, T);
+    double W[3][3];
+    tri_state(tv, w, W);
+    double gu[2][2], gp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        gp[j] = W[0][2] * T.g[0][j] + W[1][2] * T.g[1][j] + W[2][2] * T.g[2][j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gu[i][j] = W[0][i] * T.g[0][j] + W[1][i] * T.g[1][j] + W[2][i] * T.g[2][j];
+    }
+    const double divu = gu[0][0] + gu[1][1];
+    const double wd = T.wd, h2 = T.h2, h = sqrt(h2);
+    double ga[2], gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ga[j] = a == 0 ? T.g[0][j] : (a == 1 ? T.g[1][j] : T.g[2][j]);
+        gb[j] = b == 0 ? T.g[0][j] : (b == 1 ? T.g[1][j] : T.g[2][j]);
+    }
+    const double gab = ga[0] * gb[0] + ga[1] * gb[1];
+    const double visc[2] = {gu[0][0] * ga[0] + gu[0][1] * ga[1], gu[1][0] * ga[0] + gu[1][1] * ga[1]};   // (grad u) g_a
+    const double guga[2] = {ga[0] * gu[0][0] + ga[1] * gu[1][0], ga[0] * gu[0][1] + ga[1] * gu[1][1]};   // g_a^T (grad u)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double u[2] = {0.0, 0.0}, p = 0.0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double ph = phi_q2(q, v);
+            u[0] += ph * W[v][0]; u[1] += ph * W[v][1]; p += ph * W[v][2];
+        }
+        const double pa = phi_q2(q, a), pb = phi_q2(q, b);
+        double tau, ctau, tauL, cL;
+        ugn_taus(u, h, h2, nu, tau, ctau, tauL, cL);
+        const double conv[2] = {gu[0][0] * u[0] + gu[0][1] * u[1], gu[1][0] * u[0] + gu[1][1] * u[1]};   // (u.grad)u
+        const double r[2] = {conv[0] + gp[0], conv[1] + gp[1]};                                         // res
+        const double sa = r[0] * ga[0] + r[1] * ga[1];
+        const double ugb = u[0] * gb[0] + u[1] * gb[1];
+        const double uga = u[0] * ga[0] + u[1] * ga[1];
+        const double tw = wd * tau, wpa = wd * pa, wpb = wd * pb;
+        double cu[2], cg[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cu[j] = wd * ctau * pb * u[j];                                     // weighted d tau / d u_(b,j)
+            cg[j] = wd * (cL * pb * u[j] * divu + tauL * gb[j]);               // weighted d (tau_LSIC div u)
+        }
+        const double A1 = wpa * ugb + (wd * nu) * gab + tw * uga * ugb;
+        const double cgu = wpa * pb + tw * uga * pb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[4 * i + j] += cgu * gu[i][j] + (cu[j] * uga + tw * pb * ga[j]) * r[i] + ga[i] * cg[j];
+            acc[5 * i] += A1;
+            acc[4 * i + 3] += tw * uga * gb[i] - wpb * ga[i];
+            acc[12 + i] += wpa * gb[i] + cu[i] * sa + tw * (ugb * ga[i] + pb * guga[i]);
+        }
+        acc[15] += tw * gab;
+        if (want_res) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                Ra[i] += wpa * conv[i] + (wd * nu) * visc[i] - (wd * p) * ga[i] + tw * uga * r[i] +
+                         (wd * tauL) * divu * ga[i];
+            Ra[3] += wpa * divu + tw * sa;
+        }
+    }
+}
+
+__device__ __forceinline__ void tri_block_accumulate_stokes(const int4 tv, const double* __restrict__ pts,
+                                                            const double* __restrict__ w, double nu_s, double beta,
+                                                            int a, int b, bool want_res, double acc[16], double Ra[4]) {
+    TriGeom T;
+    tri_geometry(tv, pts, T);
+    const double wd = T.wd, vol = 3.0 * wd, muT = beta * T.h2;
+    double ga[2], gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ga[j] = a == 0 ? T.g[0][j] : (a == 1 ? T.g[1][j] : T.g[2][j]);
+        gb[j] = b == 0 ? T.g[0][j] : (b == 1 ? T.g[1][j] : T.g[2][j]);
+    }
+    const double gab = ga[0] * gb[0] + ga[1] * gb[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        acc[5 * i] += nu_s * vol * gab;                 // nu_s (grad u, grad v)
+        acc[4 * i + 3] += -wd * ga[i];                  // -(p, div v), int phi_b = vol / 3 = wd
+        acc[12 + i] += wd * gb[i];                      // +(div u, q)
+    }
+    acc[15] += muT * vol * gab;
+    if (want_res) {
+        double W[3][3];
+        tri_state(tv, w, W);
+        double gu[2][2], gp[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gp[j] = W[0][2] * T.g[0][j] + W[1][2] * T.g[1][j] + W[2][2] * T.g[2][j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gu[i][j] = W[0][i] * T.g[0][j] + W[1][i] * T.g[1][j] + W[2][i] * T.g[2][j];
+        }
+        const double psum = W[0][2] + W[1][2] + W[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Ra[i] += nu_s * vol * (gu[i][0] * ga[0] + gu[i][1] * ga[1]) - wd * ga[i] * psum;
+        Ra[3] += wd * (gu[0][0] + gu[1][1]) + muT * vol * (gp[0] * ga[0] + gp[1] * ga[1]);
+    }
+}
+
+// one interface for the four forms (aux: Stokes 2-D pressure-stabilisation coefficient beta; nu: 1/Re, or the
+// Stokes 2-D viscosity)
+template <int FORM, bool corrected>
+__device__ __forceinline__ void block_accumulate(const int4 tv, const double* __restrict__ pts,
+                                                 const double* __restrict__ w, double nu, double aux, int a, int b,
+                                                 bool want_res, double acc[16], double Ra[4]) {
+    if constexpr (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tv, pts, w, a, b, want_res, acc, Ra);
+    else if constexpr (FORM == SNS_FORM_NS) tet_block_accumulate<corrected>(tv, pts, w, nu, a, b, want_res, acc, Ra);
+    else if constexpr (FORM == SNS_FORM_STOKES_2D) tri_block_accumulate_stokes(tv, pts, w, nu, aux, a, b, want_res, acc, Ra);
+    else tri_block_accumulate_ugn(tv, pts, w, nu, a, b, want_res, acc, Ra);
+}
+constexpr bool form_is_linear(int form) { return form == SNS_FORM_STOKES || form == SNS_FORM_STOKES_2D; }
+
 // off-diagonal BSR blocks: one lane per slot, slots taken from the host's count-sorted list
 template <int FORM, bool corrected>
 __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32_t* __restrict__ od_order,
@@ -643,7 +847,7 @@ __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32
                                                        const int32_t* __restrict__ tets,
                                                        const double* __restrict__ pts, const double* __restrict__ w,
                                                        const uint8_t* __restrict__ bc_mask, double nu,
-                                                       double* __restrict__ vals) {
+                                                       double aux, double* __restrict__ vals) {
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= n_od) return;
     const int64_t s = od_order[lane];
@@ -668,8 +872,7 @@ __global__ __launch_bounds__(256) void k_fused_offdiag(int64_t n_od, const int32
             id = (uint32_t)c_idx[k];
             tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
         }
-        if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
-        else tet_block_accumulate<corrected>(tvc, pts, w, nu, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
+        block_accumulate<FORM, corrected>(tvc, pts, w, nu, aux, (idc >> 2) & 3, idc & 3, false, acc, nullptr);
     }
     const uchar4 mr = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)row);
     const uchar4 mc = *reinterpret_cast<const uchar4*>(bc_mask + 4 * (int64_t)col);
@@ -691,7 +894,7 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
                                                     const int32_t* __restrict__ c_idx,
                                                     const int32_t* __restrict__ tets, const double* __restrict__ pts,
                                                     const double* __restrict__ w, const uint8_t* __restrict__ bc_mask,
-                                                    const double* __restrict__ bc_val, double nu,
+                                                    const double* __restrict__ bc_val, double nu, double aux,
                                                     double* __restrict__ vals, double* __restrict__ F) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t node = gid >> 2;
@@ -719,8 +922,7 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
                 id = (uint32_t)c_idx[k];
                 tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
             }
-            if (FORM == SNS_FORM_STOKES) tet_block_accumulate_stokes(tvc, pts, w, a, a, true, acc, R);
-            else tet_block_accumulate<corrected>(tvc, pts, w, nu, a, a, true, acc, R);
+            block_accumulate<FORM, corrected>(tvc, pts, w, nu, aux, a, a, true, acc, R);
         }
     }
     // quad sums: (l0 + l1) + (l2 + l3), identical on every lane
@@ -749,19 +951,21 @@ __global__ __launch_bounds__(256) void k_fused_diag(int32_t n_rows, const int32_
         const unsigned char rbq = q == 0 ? mb[0] : (q == 1 ? mb[1] : (q == 2 ? mb[2] : mb[3]));
         row[d] = (rbq | mb[d]) ? ((q == d) ? 1.0 : 0.0) : v;
     }
-    double2* o = reinterpret_cast<double2*>(vals + 16 * s + 4 * q);
-    o[0] = make_double2(row[0], row[1]);
-    o[1] = make_double2(row[2], row[3]);
+    if (vals) {
+        double2* o = reinterpret_cast<double2*>(vals + 16 * s + 4 * q);
+        o[0] = make_double2(row[0], row[1]);
+        o[1] = make_double2(row[2], row[3]);
+    }
     if (F) {
         const int64_t dof = 4 * node + q;
         const double rq = q == 0 ? R[0] : (q == 1 ? R[1] : (q == 2 ? R[2] : R[3]));
-        F[dof] = bc_mask[dof] ? ((FORM == SNS_FORM_STOKES ? 0.0 : w[dof]) - bc_val[dof]) : rq;
+        F[dof] = bc_mask[dof] ? ((form_is_linear(FORM) ? 0.0 : w[dof]) - bc_val[dof]) : rq;
     }
 }
 // Lifting term of a state that violates its Dirichlet data (:65): F_free += A0[:,B] (g - x_B), A0 = the unconstrained
 // Jacobian.  Same work split as k_fused_diag (4 lanes per node, DPP quad sums); only tets with a violated Dirichlet
 // dof (dl != 0 on one of their nodes) cost anything: their blocks (a,b) are recomputed and applied to dl_b.
-template <bool corrected>
+template <int FORM, bool corrected>
 __global__ __launch_bounds__(256) void k_fused_lift(int32_t n_rows, const int32_t* __restrict__ diag,
                                                     const int64_t* __restrict__ c_ptr,
                                                     const int32_t* __restrict__ c_idx,
@@ -780,15 +984,16 @@ __global__ __launch_bounds__(256) void k_fused_lift(int32_t n_rows, const int32_
             const int a = (id >> 2) & 3;
             const int4 tv = *reinterpret_cast<const int4*>(tets + 4 * (int64_t)(id >> 4));
             const int32_t nd[4] = {tv.x, tv.y, tv.z, tv.w};
+            constexpr int NPE = (FORM == SNS_FORM_UGN_2D || FORM == SNS_FORM_STOKES_2D) ? 3 : 4;
 #pragma unroll 1
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NPE; ++b) {
                 const double2* dp = reinterpret_cast<const double2*>(dl + 4 * (int64_t)nd[b]);
                 const double2 d01 = dp[0], d23 = dp[1];
                 if (d01.x == 0.0 && d01.y == 0.0 && d23.x == 0.0 && d23.y == 0.0) continue;
                 double blk[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) blk[e] = 0.0;
-                tet_block_accumulate<corrected>(tv, pts, w, nu, a, b, false, blk, nullptr);
+                block_accumulate<FORM, corrected>(tv, pts, w, nu, 0.0, a, b, false, blk, nullptr);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     R[c] += blk[4 * c] * d01.x + blk[4 * c + 1] * d01.y + blk[4 * c + 2] * d23.x + blk[4 * c + 3] * d23.y;
@@ -807,10 +1012,12 @@ __global__ __launch_bounds__(256) void k_fused_lift(int32_t n_rows, const int32_
     const double rq = q == 0 ? R[0] : (q == 1 ? R[1] : (q == 2 ? R[2] : R[3]));
     if (!bc_mask[dof]) F[dof] += rq;
 }
-template __global__ void k_fused_lift<false>(int32_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*,
-                                             const double*, const double*, const uint8_t*, const double*, double, double*);
-template __global__ void k_fused_lift<true>(int32_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*,
-                                            const double*, const double*, const uint8_t*, const double*, double, double*);
+#define SNS_INST_LIFT(FM, C)                                                                                        \
+    template __global__ void k_fused_lift<FM, C>(int32_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
+                                                 const double*, const double*, const uint8_t*, const double*, double, double*);
+SNS_INST_LIFT(SNS_FORM_NS, false)
+SNS_INST_LIFT(SNS_FORM_NS, true)
+SNS_INST_LIFT(SNS_FORM_UGN_2D, false)
 
 // dl = g - w on Dirichlet dofs, 0 elsewhere
 __global__ __launch_bounds__(256) void k_bc_defect(int64_t ndof, const uint8_t* __restrict__ bc_mask,
@@ -823,13 +1030,84 @@ __global__ __launch_bounds__(256) void k_bc_defect(int64_t ndof, const uint8_t* 
 #define SNS_INST_FUSED(FM, C)                                                                                      \
     template __global__ void k_fused_offdiag<FM, C>(int64_t, const int32_t*, const int64_t*, const int32_t*, const int32_t*, \
                                                 const int32_t*, const int32_t*, const double*, const double*,       \
-                                                const uint8_t*, double, double*);                                   \
+                                                const uint8_t*, double, double, double*);                           \
     template __global__ void k_fused_diag<FM, C>(int32_t, const int32_t*, const int64_t*, const int32_t*,               \
                                              const int32_t*, const double*, const double*, const uint8_t*,          \
-                                             const double*, double, double*, double*);
+                                             const double*, double, double, double*, double*);
 SNS_INST_FUSED(SNS_FORM_NS, false)
 SNS_INST_FUSED(SNS_FORM_NS, true)
 SNS_INST_FUSED(SNS_FORM_STOKES, false)
+SNS_INST_FUSED(SNS_FORM_STOKES_2D, false)
+SNS_INST_FUSED(SNS_FORM_UGN_2D, false)
+
+// residual-only pass of the 2-D UGN form: one lane per triangle, Fe[16 t + 4 a + c] (same layout as the tet kernel,
+// so k_gather_residual serves both)
+__global__ __launch_bounds__(256) void k_residual_tri(int64_t n_tris, const int32_t* __restrict__ tets,
+                                                      const double* __restrict__ pts, const double* __restrict__ w,
+                                                      double nu, double* __restrict__ Fe) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const int4 tv = *reinterpret_cast<const int4*>(tets + 4 * t);
+    TriGeom T;
+    tri_geometry(tv, pts, T);
+    double W[3][3];
+    tri_state(tv, w, W);
+    double gu[2][2], gp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        gp[j] = W[0][2] * T.g[0][j] + W[1][2] * T.g[1][j] + W[2][2] * T.g[2][j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gu[i][j] = W[0][i] * T.g[0][j] + W[1][i] * T.g[1][j] + W[2][i] * T.g[2][j];
+    }
+    const double divu = gu[0][0] + gu[1][1];
+    const double wd = T.wd, h2 = T.h2, h = sqrt(h2);
+    double R[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[a][c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double u[2] = {0.0, 0.0}, p = 0.0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double ph = phi_q2(q, v);
+            u[0] += ph * W[v][0]; u[1] += ph * W[v][1]; p += ph * W[v][2];
+        }
+        double tau, ctau, tauL, cL;
+        ugn_taus(u, h, h2, nu, tau, ctau, tauL, cL);
+        const double conv[2] = {gu[0][0] * u[0] + gu[0][1] * u[1], gu[1][0] * u[0] + gu[1][1] * u[1]};
+        const double r[2] = {conv[0] + gp[0], conv[1] + gp[1]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double pa = phi_q2(q, a);
+            const double sa = r[0] * T.g[a][0] + r[1] * T.g[a][1];
+            const double uga = u[0] * T.g[a][0] + u[1] * T.g[a][1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double visc = gu[i][0] * T.g[a][0] + gu[i][1] * T.g[a][1];
+                R[a][i] += conv[i] * pa + nu * visc - p * T.g[a][i] + tau * uga * r[i] + tauL * divu * T.g[a][i];
+            }
+            R[a][2] += pa * divu + tau * sa;
+        }
+    }
+    double2* o = reinterpret_cast<double2*>(Fe + 16 * t);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[2 * a] = make_double2(wd * R[a][0], wd * R[a][1]);
+        o[2 * a + 1] = make_double2(0.0, wd * R[a][2]);
+    }
+    o[6] = make_double2(0.0, 0.0);
+    o[7] = make_double2(0.0, 0.0);
+}
+
+// F_B = w_B - g on Dirichlet dofs (set_bc(F, bc, x, -1)); other entries untouched
+__global__ __launch_bounds__(256) void k_bc_residual(int64_t ndof, const uint8_t* __restrict__ bc_mask,
+                                                     const double* __restrict__ bc_val, const double* __restrict__ w,
+                                                     double* __restrict__ F) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndof; i += (int64_t)gridDim.x * blockDim.x)
+        if (bc_mask[i]) F[i] = w[i] - bc_val[i];
+}
 
 // Residual-only element pass for states that already satisfy the Dirichlet data (no lifting term):
 // ONE LANE PER TET, every lane busy (the fused kernel keeps 12 of 16 lanes idle in its per-point

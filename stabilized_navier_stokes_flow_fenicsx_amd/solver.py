@@ -50,7 +50,9 @@ class NewtonResult:
 
 
 class FlowProblem:
-    """Mesh + Dirichlet data + operator hierarchy on one GPU (one per rank).
+    """Mesh + Dirichlet data + operator hierarchy on one GPU (one per rank).  ``mesh`` is a ``TetMesh`` (3-D
+    G-metric forms) or a ``mesh2d.TriMesh`` (2-D UGN forms of the lid-driven / DFG-2D scripts; "stokes" and "ns"
+    then name the 2-D forms, see sns_create_2d in include/sns.h).
 
     Replaces what ``functionspace`` / ``dirichletbc`` / ``create_matrix`` /
     ``fem.form`` build for the reference (:127-147, :45-46, :271-272).
@@ -70,14 +72,26 @@ class FlowProblem:
         self.bc_mask = np.ascontiguousarray(mask, dtype=np.uint8)
         self.bc_val = np.ascontiguousarray(g, dtype=np.float64)
         self.options = options if options is not None else default_options(**opt_kw)
+        self.dim = int(getattr(mesh, "dim", 3))
         pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
-        tets = np.ascontiguousarray(mesh.tets, dtype=np.int32)
+        tets = np.ascontiguousarray(mesh.tris if self.dim == 2 else mesh.tets, dtype=np.int32)
         if self.bc_mask.shape != (4 * len(pts),) or self.bc_val.shape != (4 * len(pts),):
             raise ValueError("bc arrays must have 4*num_nodes entries")
+        if pts.shape[1] != self.dim or tets.shape[1] != self.dim + 1:
+            raise ValueError("mesh arrays do not match the mesh dimension")
+        if self.dim == 2:
+            if part is not None:
+                raise ValueError("2-D problems run on a single GPU (no partition)")
+            # the unused z component is a homogeneous Dirichlet dof (libsns.so imposes the same)
+            self.bc_mask = self.bc_mask.copy()
+            self.bc_val = self.bc_val.copy()
+            self.bc_mask[2::4] = 1
+            self.bc_val[2::4] = 0.0
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        check(self.lib.sns_create(C.byref(h), len(pts), len(tets), pts.ctypes.data, tets.ctypes.data,
-                                  self.bc_mask.ctypes.data, self.bc_val.ctypes.data, idx, C.byref(self.options)))
+        create = self.lib.sns_create_2d if self.dim == 2 else self.lib.sns_create
+        check(create(C.byref(h), len(pts), len(tets), pts.ctypes.data, tets.ctypes.data,
+                     self.bc_mask.ctypes.data, self.bc_val.ctypes.data, idx, C.byref(self.options)))
         self.h = h
         self.n_local = len(pts)
         self.n_owned = len(pts)

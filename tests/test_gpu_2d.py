@@ -1,0 +1,170 @@
+"""GPU parity of the 2-D triangle P1-P1 UGN path -- the ONE part of the path the reference pins:
+Validation_Flow/DFG_2D_Validation.py:202-203 holds C_d = 5.57953523384, C_l = 0.010618948146 for the form of
+:141-163 (== LidDrivenFlow/LidDrivenNavierStokesFlow.py:123-143) and the functional of :195-200.
+
+HIP (through the C-ABI, sns_create_2d) vs the literal oracle (oracle/forms2d.py: every UFL operator spelled out,
+Jacobian by autograd): element / global operators to 1e-12, Stokes and Newton fields to 1e-8, then the mesh series
+whose drag and lift converge to the reference's constants."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel
+from oracle import forms2d as F2
+from stabilized_navier_stokes_flow_fenicsx_amd import mesh2d as M2
+from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+
+pytestmark = pytest.mark.gpu
+NU = 1e-3                                            # DFG_2D_Validation.py:148
+
+
+def _disjoint_triangles(k, rng, scale):
+    X = rng.normal(size=(k, 3, 2)) * scale
+    pts = X.reshape(-1, 2)
+    tris = np.arange(3 * k, dtype=np.int32).reshape(k, 3)
+    return M2.TriMesh(pts, tris, np.zeros((0, 2), np.int32), np.zeros(0, np.int32))
+
+
+@pytest.mark.parametrize("nu,uscale,scale", [(1e-3, 1.0, 0.01), (1e-3, 1e-3, 0.05), (0.1, 0.3, 1.0), (1.0, 5.0, 0.2),
+                                              (1e-2, 0.0, 0.1)])
+def test_element_blocks_match_literal_forms(nu, uscale, scale):
+    """One mesh of disjoint random triangles: the assembled operator IS the set of element matrices.  The cases
+    cover both branches of both conditionals (|u| <= 1e-8: uscale 0; Re_UGN <= 3 and > 3)."""
+    rng = np.random.default_rng(11)
+    m = _disjoint_triangles(40, rng, scale)
+    w = rng.normal(size=m.num_dofs)
+    w.reshape(-1, 4)[:, :2] *= uscale
+    w[2::4] = 0.0
+    mask = np.zeros(m.num_dofs, np.uint8)
+    g = np.zeros(m.num_dofs)
+    P = FlowProblem(m, (mask, g), reynolds=1.0 / nu)
+    F = P.zeros()
+    P.jacobian(torch.from_numpy(w).cuda(), "ns", residual_out=F)
+    Jo, Fo = F2.assemble_ugn(m.points, m.tris, w, nu, mask, g)
+    Jh = P.to_scipy()
+    assert abs(Jh - Jo).max() <= 1e-12 * abs(Jo).max()
+    assert rel(F.cpu().numpy(), Fo) < 1e-12
+    Fr = P.residual(torch.from_numpy(w).cuda(), "ns")               # residual-only kernel (one lane per triangle)
+    assert rel(Fr.cpu().numpy(), Fo) < 1e-12
+    P.close()
+
+
+@pytest.mark.parametrize("nu_s,beta", [(1.0, 0.2), (0.01, 1.0 / (12 * 0.01))])
+def test_stokes2d_operator_and_solve(nu_s, beta):
+    """Both Stokes variants of the 2-D scripts (DFG: unit viscosity, 0.2 h^2; cavity: nu, h^2/(12 nu))."""
+    m = M2.rectangle_mesh(12)
+    mask, g = M2.cavity2d_bcs(m).flatten()
+    P = FlowProblem(m, (mask, g), stokes_viscosity=nu_s, stokes_beta=beta, ksp_rtol=1e-12)
+    U, res = P.stokes_solve()
+    Ao, bo = F2.assemble_stokes2d(m.points, m.tris, mask, g, nu_s, beta)
+    assert abs(P.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+    Uo = F2.solve_stokes2d(m.points, m.tris, mask, g, nu_s, beta)
+    assert res.reason > 0
+    assert rel(U.cpu().numpy(), Uo) < 1e-8
+    # linear residual A w - b at an arbitrary state (the .F callback of the linear form)
+    w = np.random.default_rng(5).normal(size=m.num_dofs)
+    w[2::4] = 0.0
+    Fr = P.residual(torch.from_numpy(w).cuda(), "stokes").cpu().numpy()
+    B = F2.full_mask(mask).astype(bool)
+    ws = np.where(B, np.where(np.arange(len(g)) % 4 == 2, 0.0, g), w)
+    ref = Ao @ ws - bo
+    ref[B] = (w - np.where(np.arange(len(g)) % 4 == 2, 0.0, g))[B]
+    assert rel(Fr, ref) < 1e-11
+    P.close()
+
+
+def test_global_jacobian_and_residual_with_and_without_lifting():
+    m = M2.dfg_2d_mesh(0.5)
+    mask, g = M2.dfg2d_bcs(m).flatten()
+    rng = np.random.default_rng(2)
+    P = FlowProblem(m, (mask, g), reynolds=1.0 / NU)
+    for violate in (False, True):
+        w = 0.2 * rng.normal(size=m.num_dofs)
+        w[2::4] = 0.0
+        if not violate:
+            B = F2.full_mask(mask).astype(bool)
+            w[B] = np.where(np.arange(len(g)) % 4 == 2, 0.0, g)[B]
+        wd = torch.from_numpy(w).cuda()
+        F = P.zeros()
+        P.jacobian(wd, "ns", residual_out=F)
+        Jo, Fo = F2.assemble_ugn(m.points, m.tris, w, NU, mask, g)
+        assert abs(P.to_scipy() - Jo).max() <= 1e-12 * abs(Jo).max()
+        assert rel(F.cpu().numpy(), Fo) < 1e-12
+        assert rel(P.residual(wd, "ns").cpu().numpy(), Fo) < 1e-12
+    P.close()
+
+
+def test_dfg2d_newton_fields_and_coefficients_match_oracle():
+    """Same mesh, same Dirichlet data: Newton on the GPU (BiCGStab + AMG) vs the oracle's LU-Newton."""
+    m = M2.dfg_2d_mesh(1.0)
+    mask, g = M2.dfg2d_bcs(m).flatten()
+    Uo = F2.solve_stokes2d(m.points, m.tris, mask, g)
+    P = FlowProblem(m, (mask, g), reynolds=1.0 / NU, ksp_rtol=1e-10, snes_rtol=1e-12, snes_atol=1e-11)
+    U, res = P.stokes_solve()
+    assert res.reason > 0 and rel(U.cpu().numpy(), Uo) < 1e-6
+    w0 = Uo.copy()
+    w0[3::4] *= NU                                                  # Stokes pressure of viscosity NU
+    wo, info = F2.newton2d(m.points, m.tris, w0, NU, mask, g)
+    assert info["converged"]
+    w, nres = P.newton_solve(torch.from_numpy(w0).cuda())
+    assert nres.reason > 0
+    wh = w.cpu().numpy()
+    W, Wo = wh.reshape(-1, 4), wo.reshape(-1, 4)
+    assert rel(W[:, :2], Wo[:, :2]) < 1e-6                          # north_star's velocity tolerance
+    assert rel(W[:, 3], Wo[:, 3]) < 1e-6
+    cd, cl = M2.drag_lift_2d(m, wh, NU)
+    cdo, clo = F2.drag_lift_loops(m.points, m.tris, m.facets[m.find(M2.DFG2D_TAGS["obstacle"])], wo, NU)
+    assert abs(cd - cdo) < 1e-6 * abs(cdo) and abs(cl - clo) < 1e-5 * abs(clo) + 1e-9
+    P.close()
+
+
+def _dfg_run(n):
+    m = M2.dfg_2d_mesh(n)
+    mask, g = M2.dfg2d_bcs(m).flatten()
+    P = FlowProblem(m, (mask, g), reynolds=1.0 / NU)
+    U, res = P.stokes_solve()
+    assert res.reason > 0
+    U.view(-1, 4)[:, 3] *= NU
+    w, nres = P.newton_solve(U)
+    assert nres.reason > 0, (n, nres)
+    cd, cl = M2.drag_lift_2d(m, w.cpu().numpy(), NU)
+    P.close()
+    return m.num_cells, cd, cl, nres
+
+
+def test_dfg2d_series_converges_to_the_reference_constants():
+    """THE pin: C_d -> 5.57953523384, C_l -> 0.010618948146 (DFG_2D_Validation.py:202-203) under uniform refinement
+    of the built-in mesh (levels 2, 4, 8, 16 = 26 k ... 1.5 M triangles).  Tolerances state what the P1-P1 UGN form
+    delivers with the script's boundary-integral functional (first order in h): the drag error at least halves...
+    per level and ends below 0.5 %, the lift ends within 10 %."""
+    out = [(n,) + _dfg_run(n) for n in (2, 4, 8, 16)]
+    for n, cells, cd, cl, nres in out:
+        print(f"  DFG-2D level {n}: {cells} triangles, C_d {cd:.6f} ({100 * (cd / M2.DFG2D_CD_REF - 1):+.3f} %), "
+              f"C_l {cl:.6f} ({100 * (cl / M2.DFG2D_CL_REF - 1):+.2f} %), Newton {nres.its} its, {nres.ksp_its} ksp its, "
+              f"{nres.seconds:.2f} s")
+    ed = [abs(cd - M2.DFG2D_CD_REF) for _, _, cd, _, _ in out]
+    el = [abs(cl - M2.DFG2D_CL_REF) for _, _, _, cl, _ in out]
+    assert ed[1] < 0.6 * ed[0] and ed[2] < 0.6 * ed[1] and ed[3] < 0.6 * ed[2]
+    assert ed[3] < 0.005 * M2.DFG2D_CD_REF
+    assert el[3] < 0.10 * M2.DFG2D_CL_REF and el[3] < el[0]
+
+
+def test_lid_driven_cavity_2d_matches_oracle():
+    """LidDrivenNavierStokesFlow.py <Re=100> <NumCells=24>: Stokes (nu, h^2/(12 nu)) then NS, vs the oracle."""
+    Re, nc = 100.0, 24
+    nu = 1.0 / Re
+    m = M2.rectangle_mesh(nc)
+    mask, g = M2.cavity2d_bcs(m).flatten()
+    P = FlowProblem(m, (mask, g), reynolds=Re, stokes_viscosity=nu, stokes_beta=(1.0 / 3.0) / (4 * nu),
+                    ksp_rtol=1e-10, snes_rtol=1e-12, snes_atol=1e-11)
+    U, res = P.stokes_solve()
+    Uo = F2.solve_stokes2d(m.points, m.tris, mask, g, nu, (1.0 / 3.0) / (4 * nu))
+    assert res.reason > 0 and rel(U.cpu().numpy(), Uo) < 1e-6
+    wo, info = F2.newton2d(m.points, m.tris, Uo, nu, mask, g)
+    assert info["converged"]
+    w, nres = P.newton_solve(torch.from_numpy(Uo.copy()).cuda())
+    assert nres.reason > 0
+    W, Wo = w.cpu().numpy().reshape(-1, 4), wo.reshape(-1, 4)
+    assert rel(W[:, :2], Wo[:, :2]) < 1e-6 and rel(W[:, 3], Wo[:, 3]) < 1e-6
+    assert np.all(W[:, 2] == 0.0)
+    P.close()
