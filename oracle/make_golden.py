@@ -23,6 +23,53 @@ from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M  # noq
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
+def make_golden_2d():
+    """2-D UGN path (LidDrivenNavierStokesFlow.py:123-143 == DFG_2D_Validation.py:141-163), the part of the oracle
+    the reference's own constants pin (DFG_2D_Validation.py:202-203):
+      ugn2d_elements.npz   literal residual / autograd Jacobian of 14 triangles covering both branches of both
+                           conditionals (|u| <= 1e-8, Re_UGN <= 3 / > 3), literal Stokes matrices (both variants)
+      cavity2d_8.npz       LidDrivenNavierStokesFlow.py 50 8: Stokes (LU) and Newton fields, ||dx|| history
+      dfg2d_level05.npz    DFG 2D-1 on the built-in level-0.5 mesh: Newton field, C_d, C_l of the oracle"""
+    from oracle import forms2d as F2
+    from stabilized_navier_stokes_flow_fenicsx_amd import mesh2d as M2
+    rng = np.random.default_rng(20260202)
+    X, W, NU = [], [], []
+    for k in range(14):
+        X.append(rng.normal(size=(3, 2)) * [1.0, 0.05, 0.01, 0.3][k % 4])
+        w = rng.normal(size=(3, 3))
+        w[:, :2] *= [1.0, 1e-3, 5.0, 0.0, 1e-9, 0.2, 30.0][k % 7]
+        W.append(w)
+        NU.append([1e-3, 1e-2, 1.0, 0.1, 1e-3, 0.5, 1e-3][k % 7])
+    X, W, NU = np.array(X), np.array(W), np.array(NU)
+    import torch
+    F = np.zeros((14, 9)); J = np.zeros((14, 9, 9)); A1 = np.zeros((14, 9, 9)); A2 = np.zeros((14, 9, 9))
+    for i in range(14):
+        Xi, wi = torch.as_tensor(X[i]), torch.as_tensor(W[i].reshape(9))
+        F[i] = F2.ugn_residual_one(Xi, wi, float(NU[i])).numpy()
+        J[i] = torch.autograd.functional.jacobian(lambda ww: F2.ugn_residual_one(Xi, ww, float(NU[i])), wi).numpy()
+        A1[i] = F2.stokes_matrix_one(Xi, 1.0, 0.2).numpy()
+        A2[i] = F2.stokes_matrix_one(Xi, float(NU[i]), 1.0 / (12.0 * float(NU[i]))).numpy()
+    np.savez(os.path.join(OUT, "ugn2d_elements.npz"), X=X, W=W, nu=NU, F=F, J=J, A_dfg=A1, A_cavity=A2)
+
+    Re, nc = 50.0, 8
+    nu = 1.0 / Re
+    m = M2.rectangle_mesh(nc)
+    mask, g = M2.cavity2d_bcs(m).flatten()
+    U = F2.solve_stokes2d(m.points, m.tris, mask, g, nu, (1.0 / 3.0) / (4 * nu))
+    w, info = F2.newton2d(m.points, m.tris, U, nu, mask, g)
+    np.savez(os.path.join(OUT, "cavity2d_8.npz"), points=m.points, tris=m.tris, mask=mask, g=g, Re=Re, U_stokes=U,
+             w_newton=w, its=info["its"], hist=np.array(info["hist"]))
+
+    m = M2.dfg_2d_mesh(0.5)
+    mask, g = M2.dfg2d_bcs(m).flatten()
+    U = F2.solve_stokes2d(m.points, m.tris, mask, g)
+    U[3::4] *= 1e-3
+    w, info = F2.newton2d(m.points, m.tris, U, 1e-3, mask, g)
+    cd, cl = F2.drag_lift_loops(m.points, m.tris, m.facets[m.find(M2.DFG2D_TAGS["obstacle"])], w, 1e-3)
+    np.savez(os.path.join(OUT, "dfg2d_level05.npz"), points=m.points, tris=m.tris, facets=m.facets,
+             facet_tags=m.facet_tags, mask=mask, g=g, w_newton=w, its=info["its"], cd=cd, cl=cl)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20260101)
@@ -62,6 +109,7 @@ def main():
     wN, info = S.newton(m.points, m.tets, U, 10.0, mask, g)
     np.savez(os.path.join(OUT, "duct_8x2x2.npz"), points=m.points, tets=m.tets, mask=mask, g=g, U_stokes=U,
              w_newton=wN, Re=10.0, fnorms=np.array(info["fnorms"]), its=info["its"], reason=info["reason"])
+    make_golden_2d()
     print("wrote", sorted(os.listdir(OUT)))
 
 

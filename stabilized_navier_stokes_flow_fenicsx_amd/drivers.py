@@ -146,39 +146,61 @@ def write_run_metadata(folder, Re, img_fname, flowrate_ratio, channel_mesh_size,
 
 
 def write_xdmf(path_noext: str, msh, name: str, values: np.ndarray):
-    """P1 nodal field as XDMF + raw little-endian binaries (``write_mesh`` +
-    ``write_function`` of :333-341).  The reference stores heavy data in HDF5;
-    h5py is not available offline, so the heavy data are ``Format="Binary"`` items
-    -- same XDMF structure, same Grid/Attribute names (Velocity / Pressure)."""
+    """P1 nodal field as ``<path>.xdmf`` + ``<path>.h5`` -- ``XDMFFile.write_mesh`` + ``write_function`` of
+    :333-341.  Same container layout as dolfinx 0.9 writes: ``/Mesh/mesh/geometry`` (N x gdim float64),
+    ``/Mesh/mesh/topology`` (E x nodes-per-cell int64), ``/Function/<name>/0`` (N x ncomp float64; a scalar is
+    N x 1), the light data pointing into it with ``Format="HDF"`` items -- so the reference's consumer
+    (streamtrace.py:87-96: ``h5f["Function"][name]["0"]``) and ParaView open it unchanged.  h5py does not exist
+    offline; the container is written by ``h5lite`` (file-format spec, v1 objects)."""
+    from .h5lite import H5Writer
     base = os.path.basename(path_noext)
-    values = np.ascontiguousarray(values, dtype="<f8")
-    geo, topo, dat = path_noext + "_geometry.bin", path_noext + "_topology.bin", path_noext + f"_{name}.bin"
-    np.ascontiguousarray(msh.points, dtype="<f8").tofile(geo)
-    np.ascontiguousarray(msh.tets, dtype="<i4").tofile(topo)
-    values.tofile(dat)
-    ncomp = 1 if values.ndim == 1 else values.shape[1]
+    dim = int(getattr(msh, "dim", 3))
+    cells = msh.tris if dim == 2 else msh.tets
+    values = np.asarray(values, dtype=np.float64)
+    vals2 = values.reshape(len(values), -1)
+    ncomp = vals2.shape[1]
+    w = H5Writer()
+    w.dataset("/Mesh/mesh/geometry", np.asarray(msh.points, dtype=np.float64))
+    w.dataset("/Mesh/mesh/topology", np.asarray(cells, dtype=np.int64))
+    w.dataset(f"/Function/{name}/0", vals2)
+    w.write(path_noext + ".h5")
     atype = "Scalar" if ncomp == 1 else "Vector"
-    dims = f"{msh.num_nodes} {ncomp}" if ncomp > 1 else f"{msh.num_nodes}"
+    ttype, npe, gtype = ("Triangle", 3, "XY") if dim == 2 else ("Tetrahedron", 4, "XYZ")
+    ncell, nn = len(cells), msh.num_nodes
     xml = f"""<?xml version="1.0"?>
 <!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>
 <Xdmf Version="3.0" xmlns:xi="https://www.w3.org/2001/XInclude">
   <Domain>
     <Grid Name="mesh" GridType="Uniform">
-      <Topology TopologyType="Tetrahedron" NumberOfElements="{msh.num_tets}" NodesPerElement="4">
-        <DataItem Dimensions="{msh.num_tets} 4" NumberType="Int" Precision="4" Format="Binary" Endian="Little">{base}_topology.bin</DataItem>
+      <Topology TopologyType="{ttype}" NumberOfElements="{ncell}" NodesPerElement="{npe}">
+        <DataItem Dimensions="{ncell} {npe}" NumberType="Int" Format="HDF">{base}.h5:/Mesh/mesh/topology</DataItem>
       </Topology>
-      <Geometry GeometryType="XYZ">
-        <DataItem Dimensions="{msh.num_nodes} 3" NumberType="Float" Precision="8" Format="Binary" Endian="Little">{base}_geometry.bin</DataItem>
+      <Geometry GeometryType="{gtype}">
+        <DataItem Dimensions="{nn} {dim}" Format="HDF">{base}.h5:/Mesh/mesh/geometry</DataItem>
       </Geometry>
-      <Attribute Name="{name}" AttributeType="{atype}" Center="Node">
-        <DataItem Dimensions="{dims}" NumberType="Float" Precision="8" Format="Binary" Endian="Little">{base}_{name}.bin</DataItem>
-      </Attribute>
+    </Grid>
+    <Grid Name="{name}" GridType="Collection" CollectionType="Temporal">
+      <Grid Name="{name}" GridType="Uniform">
+        <xi:include xpointer="xpointer(/Xdmf/Domain/Grid[@GridType='Uniform'][1]/*[self::Topology or self::Geometry])" />
+        <Time Value="0" />
+        <Attribute Name="{name}" AttributeType="{atype}" Center="Node">
+          <DataItem Dimensions="{nn} {ncomp}" Format="HDF">{base}.h5:/Function/{name}/0</DataItem>
+        </Attribute>
+      </Grid>
     </Grid>
   </Domain>
 </Xdmf>
 """
     with open(path_noext + ".xdmf", "w") as fh:
         fh.write(xml)
+
+
+def read_xdmf_function(path_noext: str, name: str):
+    """(points, cells, values) back from a ``write_xdmf`` / dolfinx file pair, the access pattern of
+    ``read_mesh_and_function`` (streamtrace.py:58-130): mesh from ``/Mesh/mesh``, data from ``/Function/<name>/0``."""
+    from .h5lite import read_datasets
+    d = read_datasets(path_noext + ".h5")
+    return d["/Mesh/mesh/geometry"], d["/Mesh/mesh/topology"], d[f"/Function/{name}/0"]
 
 
 def save_navier_stokes_solution(u, p, msh, FolderName, Re):
@@ -318,28 +340,90 @@ def duct_stokes_main(argv=None):
 
 
 def lid_driven_main(argv=None):
-    """LidDrivenNavierStokesFlow.py <Re> [<NumCells>=64] (:17-23) on the 3-D unit cube:
-    lid y=1 moving with (1,0,0), no-slip elsewhere, p=0 at the origin (:57-77); Stokes then Newton."""
+    """LidDrivenNavierStokesFlow.py <Re> [<NumCells>=64] (:17-23).
+
+    Default = the script as written: the 2-D unit square, ``create_rectangle`` triangles (:29-30), lid y=1 moving
+    with (1,0), no-slip elsewhere, p=0 at the origin (:57-77); Stokes with viscosity nu and mu_T = a0 h^2/(4 nu)
+    (:96-109) as initial guess, then the UGN-stabilised NS form (:123-143).  A trailing ``3d`` argument (or
+    SNS_CAVITY_DIM=3) runs the 3-D unit-cube extension with the G-metric form instead."""
     import torch
     from .solver import solve_navier_stokes
-    argv = sys.argv if argv is None else argv
+    argv = list(sys.argv if argv is None else argv)
+    three_d = os.environ.get("SNS_CAVITY_DIM", "2") == "3"
+    if argv and argv[-1].lower() == "3d":
+        three_d = True
+        argv = argv[:-1]
     if len(argv) not in [2, 3]:
-        raise ValueError("Usage: LidDrivenNavierStokesFlow.py <Re> [<NumCells>]")
+        raise ValueError("Usage: LidDrivenNavierStokesFlow.py <Re> [<NumCells>] [3d]")
     Re = int(argv[1])
     n = int(argv[2]) if len(argv) == 3 else 64
     t0 = time.time()
-    msh = M.cavity_mesh(n)
+    if three_d:
+        msh = M.cavity_mesh(n)
+        bcs, opt = B.cavity_bcs(msh), {}
+    else:
+        from . import mesh2d as M2
+        nu = 1.0 / Re
+        msh = M2.rectangle_mesh(n)
+        bcs, opt = M2.cavity2d_bcs(msh), dict(stokes_viscosity=nu, stokes_beta=(1.0 / 3.0) / (4.0 * nu))   # :98-100
     print(f"Pressure Degress of Freedom: {msh.num_nodes}")
     print(f"Velocity Degress of Freedom: {msh.num_nodes}")
-    P = _problem(msh, B.cavity_bcs(msh), reynolds=float(Re))
+    P = _problem(msh, bcs, reynolds=float(Re), **opt)
     U, res = P.stokes_solve()
     print("Solved Stokes Flow")
     w, u, p = solve_navier_stokes(P, U.clone(), _rank(), continuation=_continuation())
     wg = _to_global_host(P, w)
+    nd = 3 if three_d else 2
     if _rank() == 0:
         print(f"run time = {time.time() - t0: 0.2f} sec")
         write_xdmf(f"NavierStokesLidDrivenPressureLinear{Re}", msh, "Pressure", wg.reshape(-1, 4)[:, 3].copy())
-        write_xdmf(f"NavierStokesLidDrivenPressureVelocity{Re}", msh, "Velocity", wg.reshape(-1, 4)[:, :3].copy())
+        write_xdmf(f"NavierStokesLidDrivenPressureVelocity{Re}", msh, "Velocity", wg.reshape(-1, 4)[:, :nd].copy())
     r = P.last_newton
     P.close()
     return msh, wg, r
+
+
+def dfg_2d_main(argv=None):
+    """DFG_2D_Validation.py <msh file> (:22-28): Stokes with unit viscosity and mu_T = 0.2 h^2 (:101-125), NS with
+    nu = 1e-3 and the UGN stabilisation from the Stokes field (:141-187), drag / lift and their relative errors
+    against the script's constants (:195-214), XDMF output (:216-238).
+
+    ``<msh file>`` is a gmsh ASCII file of dfg_pillar_2D.geo, or ``builtin[:level]`` for the gmsh-free mesh of the
+    same geometry (mesh2d.dfg_2d_mesh).  The Stokes pressure is rescaled by nu before it seeds Newton (the unit-
+    viscosity pressure is 1/nu times too large for the NS problem; on meshes coarser than the .geo's the full
+    Newton step from the unscaled field diverges, in the oracle's LU-Newton as well); SNS_DFG_RAW_GUESS=1 keeps
+    the field exactly as the script passes it on."""
+    from . import mesh2d as M2
+    from .solver import solve_navier_stokes
+    argv = sys.argv if argv is None else argv
+    if len(argv) != 2:
+        raise ValueError("Usage: DFG_2D_Validation.py <msh file | builtin[:level]>")
+    src = argv[1]
+    if src.startswith("builtin"):
+        msh = M2.dfg_2d_mesh(float(src.split(":")[1]) if ":" in src else 4.0)
+    else:
+        msh = M2.read_msh_2d(src)
+    nu = 1e-3                                                          # :148
+    if _rank() == 0:
+        print(f"Pressure Degrees of Freedom: {msh.num_nodes}", flush=True)
+        print(f"Velocity Degrees of Freedom: {msh.num_nodes}", flush=True)
+    P = _problem(msh, M2.dfg2d_bcs(msh), reynolds=1.0 / nu, stokes_viscosity=1.0, stokes_beta=0.2,
+                 snes_rtol=1e-9, snes_stol=1e-9)
+    U, res = P.stokes_solve()
+    if _rank() == 0:
+        print("Solved Stokes Flow", flush=True)
+    if os.environ.get("SNS_DFG_RAW_GUESS", "0") != "1":
+        U.view(-1, 4)[:, 3] *= nu
+    w, u, p = solve_navier_stokes(P, U.clone(), _rank(), continuation=_continuation())
+    wg = _to_global_host(P, w)
+    cd, cl = M2.drag_lift_2d(msh, wg, nu)
+    if _rank() == 0:
+        print(f"Coefficient of Lift: {[cl]}", flush=True)
+        print(f"Cl Percent Error: {[(cl - M2.DFG2D_CL_REF) / M2.DFG2D_CL_REF]}", flush=True)
+        print(f"Coefficient of Drag: {[cd]}", flush=True)
+        print(f"Cd Percent Error: {[(cd - M2.DFG2D_CD_REF) / M2.DFG2D_CD_REF]}", flush=True)
+        write_xdmf("DFG2DValidationPressure", msh, "Pressure", wg.reshape(-1, 4)[:, 3].copy())
+        write_xdmf("DFG2DValidationVelocity", msh, "Velocity", wg.reshape(-1, 4)[:, :2].copy())
+    r = P.last_newton
+    P.close()
+    return msh, wg, (cd, cl), r

@@ -168,3 +168,47 @@ def test_lid_driven_cavity_2d_matches_oracle():
     assert rel(W[:, :2], Wo[:, :2]) < 1e-6 and rel(W[:, 3], Wo[:, 3]) < 1e-6
     assert np.all(W[:, 2] == 0.0)
     P.close()
+
+
+def test_hip_matches_committed_2d_golden_vectors():
+    """tests/golden/ugn2d_elements.npz (literal forms + autograd, oracle/make_golden.py), cavity2d_8.npz and
+    dfg2d_level05.npz against the HIP path."""
+    from conftest import golden
+    g = golden("ugn2d_elements.npz")
+    for i in range(len(g["X"])):
+        m = M2.TriMesh(g["X"][i], np.array([[0, 1, 2]], np.int32), np.zeros((0, 2), np.int32), np.zeros(0, np.int32))
+        w = np.zeros(12)
+        w.reshape(3, 4)[:, [0, 1, 3]] = g["W"][i]
+        P = FlowProblem(m, (np.zeros(12, np.uint8), np.zeros(12)), reynolds=1.0 / float(g["nu"][i]),
+                        stokes_viscosity=1.0, stokes_beta=0.2)
+        F = P.zeros()
+        P.jacobian(torch.from_numpy(w).cuda(), "ns", residual_out=F)
+        idx = (4 * np.arange(3)[:, None] + np.array([0, 1, 3])[None]).ravel()
+        J = P.to_scipy().toarray()[np.ix_(idx, idx)]
+        assert np.abs(J - g["J"][i]).max() <= 1e-12 * np.abs(g["J"][i]).max()
+        assert np.abs(F.cpu().numpy()[idx] - g["F"][i]).max() <= 1e-12 * max(np.abs(g["F"][i]).max(), 1e-300)
+        P.jacobian(None, "stokes")
+        A = P.to_scipy().toarray()[np.ix_(idx, idx)]
+        assert np.abs(A - g["A_dfg"][i]).max() <= 1e-12 * np.abs(g["A_dfg"][i]).max()
+        P.close()
+    c = golden("cavity2d_8.npz")
+    nu = 1.0 / float(c["Re"])
+    m = M2.TriMesh(c["points"], c["tris"], np.zeros((0, 2), np.int32), np.zeros(0, np.int32))
+    P = FlowProblem(m, (c["mask"], c["g"]), reynolds=float(c["Re"]), stokes_viscosity=nu, stokes_beta=1 / (12 * nu),
+                    ksp_rtol=1e-12, snes_rtol=1e-13, snes_atol=1e-12)
+    U, res = P.stokes_solve()
+    assert res.reason > 0 and rel(U.cpu().numpy(), c["U_stokes"]) < 1e-8
+    w, nres = P.newton_solve(torch.from_numpy(c["U_stokes"].copy()).cuda())
+    assert nres.reason > 0 and rel(w.cpu().numpy(), c["w_newton"]) < 1e-8
+    P.close()
+    d = golden("dfg2d_level05.npz")
+    m = M2.TriMesh(d["points"], d["tris"], d["facets"], d["facet_tags"], meta={"tags": dict(M2.DFG2D_TAGS)})
+    P = FlowProblem(m, (d["mask"], d["g"]), reynolds=1.0 / NU, ksp_rtol=1e-11, snes_rtol=1e-13, snes_atol=1e-12)
+    w0 = d["w_newton"] * 0.98
+    B = F2.full_mask(d["mask"]).astype(bool)
+    w0[B] = np.where(np.arange(len(w0)) % 4 == 2, 0.0, d["g"])[B]
+    w, nres = P.newton_solve(torch.from_numpy(w0).cuda())
+    assert nres.reason > 0 and rel(w.cpu().numpy(), d["w_newton"]) < 1e-8
+    cd, cl = M2.drag_lift_2d(m, w.cpu().numpy(), NU)
+    assert abs(cd - float(d["cd"])) < 1e-7 and abs(cl - float(d["cl"])) < 1e-7
+    P.close()

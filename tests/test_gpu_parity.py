@@ -384,13 +384,18 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
     assert (tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC0125_Box" / "Re5ChannelVelocity.xdmf").exists()
     folder = tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC02_Synthetic"
     assert (folder / "Re5ChannelVelocity.xdmf").exists() and (folder / "RunParameters.txt").exists()
-    u = np.fromfile(folder / "Re5ChannelVelocity_Velocity.bin").reshape(-1, 3)
-    assert u.shape[0] == r["msh"].num_nodes and abs(u[:, 0].max()) > 0.5
+    _, _, u = D.read_xdmf_function(str(folder / "Re5ChannelVelocity"), "Velocity")
+    assert u.shape == (r["msh"].num_nodes, 3) and abs(u[:, 0].max()) > 0.5
     msh, W, res = D.duct_stokes_main(["DuctStokesFlow.py", "ductmesh", "0.25", "2.0"])
     assert res.reason > 0 and os.path.exists("ductmesh.msh") and os.path.exists("StokesDuctVelcoity.xdmf")
     assert "L1 norm of velocity coefficient vector" in capsys.readouterr().out
-    msh, w, nres = D.lid_driven_main(["LidDrivenNavierStokesFlow.py", "10", "6"])
+    msh, w, nres = D.lid_driven_main(["LidDrivenNavierStokesFlow.py", "10", "6", "3d"])
     assert nres.reason > 0 and msh.num_tets == 6 ** 4
+    msh, w, nres = D.lid_driven_main(["LidDrivenNavierStokesFlow.py", "100", "16"])       # the script as written: 2-D
+    assert nres.reason > 0 and msh.dim == 2 and msh.num_cells == 2 * 16 * 16
+    assert os.path.exists("NavierStokesLidDrivenPressureVelocity100.h5")
+    msh, w, (cd, cl), nres = D.dfg_2d_main(["DFG_2D_Validation.py", "builtin:1"])
+    assert nres.reason > 0 and 5.2 < cd < 5.6 and "Cd Percent Error" in capsys.readouterr().out
 
 
 @pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab"), (4, "duct-rep"),
