@@ -226,6 +226,9 @@ typedef struct {
     int64_t spmv_calls; int ksp_its; int amg_levels;
 } sns_timings;
 int sns_get_timings(sns_handle h, sns_timings* t);
+/* debug counters of the LAST Krylov solve: out[0] = host<->device synchronisations (stream / event waits),
+ * out[1] = all-reduces, out[2] = neighbour (halo) exchanges, out[3] = Krylov iterations since reset_timings */
+int sns_get_counters(sns_handle h, int64_t out[4]);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot)     */
@@ -270,6 +273,12 @@ int sns_host_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets_host,
  * agg_out[n_nodes] gets the aggregate id (-1 for inactive nodes).             */
 int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind,
                        int32_t n_active, int max_agg, int32_t* agg_out, int32_t* n_agg_out);
+
+/* owned rows (i < n_owned) of a local pattern that reference a ghost column (>= n_owned): the boundary rows of the
+ * interior / boundary split of the multi-GPU SpMV -- interior rows are computed while the halo is in flight
+ * (MatMult's VecScatter overlap in the reference's PETSc).  rows_out [n_owned], *n_out entries are valid.        */
+int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind,
+                           int32_t* rows_out, int32_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ _SIGNATURES = [
     ("sns_get_element_scratch", C.c_int, [_H, C.POINTER(_P), C.POINTER(_P)]),
     ("sns_export", C.c_int, [_H, C.c_int, _P, C.c_int64]),
     ("sns_get_timings", C.c_int, [_H, C.POINTER(SnsTimings)]),
+    ("sns_get_counters", C.c_int, [_H, C.POINTER(C.c_int64)]),
     ("sns_reset_timings", C.c_int, [_H]),
     ("sns_time_kernels", C.c_int, [_H, C.c_int]),
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -93,6 +94,7 @@ _SIGNATURES = [
                                   C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
+    ("sns_host_boundary_rows", C.c_int, [C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -162,3 +164,15 @@ def host_aggregate(rowptr, colind, n_active=None, max_agg=8):
     check(lib.sns_host_aggregate(n, rowptr.ctypes.data, colind.ctypes.data, n if n_active is None else n_active,
                                  max_agg, agg.ctypes.data, C.byref(nc)))
     return agg, nc.value
+
+
+def host_boundary_rows(n_owned: int, rowptr, colind):
+    """Owned rows with a ghost column (interior / boundary split of the multi-GPU SpMV)."""
+    import numpy as np
+    lib = load()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colind = np.ascontiguousarray(colind, dtype=np.int32)
+    out = np.empty(max(1, n_owned), np.int32)
+    n = C.c_int32()
+    check(lib.sns_host_boundary_rows(n_owned, rowptr.ctypes.data, colind.ctypes.data, out.ctypes.data, C.byref(n)))
+    return out[:n.value].copy()

@@ -115,7 +115,18 @@ struct sns_ctx {
     // Newton workspace
     double *nw_F = nullptr, *nw_y = nullptr, *nw_w = nullptr, *nw_t = nullptr;
     sns_timings tm{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_it = nullptr;
+    // debug counters of the last Krylov solve (sns_get_counters): host syncs, all-reduces, halo exchanges
+    int64_t ctr_host_syncs = 0, ctr_allreduce = 0, ctr_exchange = 0;
+    int64_t last_ctr[3] = {0, 0, 0};                 // snapshot at the end of the last Krylov solve
+    int bnd_dot_blocks = 0;
+    // multi-GPU, level 0: owned rows with at least one ghost column (the only rows that must wait for the halo)
+    int32_t* bnd_rows = nullptr;
+    uint8_t* bnd_flag = nullptr;
+    int32_t n_bnd = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_x = nullptr, ev_side = nullptr;
+    bool no_overlap = false;                          // extra partial-sum blocks of the boundary pass of a split SpMV+dot
     std::unique_ptr<Comm> comm;
     // distributed coarsest level: global dense inverse, replicated on every rank
     int cg_maxn = 0;                              // padded owned coarsest nodes per rank
@@ -201,6 +212,7 @@ void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
 }
 // sum `count` device doubles over the ranks (no-op without a communicator)
 int allreduce(sns_ctx* h, double* buf_dev, int count) {
+    if (h->comm && h->comm->active()) ++h->ctr_allreduce;
     return comm_allreduce_sum(h->comm.get(), buf_dev, count, h->stream);
 }
 int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
@@ -211,6 +223,7 @@ int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
 int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
     HIP_TRY(hipMemcpyAsync(h->h_scal, src_dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    ++h->ctr_host_syncs;
     std::memcpy(out, h->h_scal, count * sizeof(double));
     return SNS_OK;
 }
@@ -219,6 +232,7 @@ int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
 int exchange_level(sns_ctx* h, int l, double* x) {
     Comm* c = h->comm.get();
     if (!c || !c->active() || c->nranks <= 1 || (size_t)l >= c->plans.size()) return SNS_OK;
+    ++h->ctr_exchange;
     return comm_exchange(c, c->plans[l], x, h->stream);
 }
 int halo_exchange(sns_ctx* h, double* x) { return exchange_level(h, 0, x); }
@@ -230,43 +244,123 @@ struct EvPair { hipEvent_t a, b; int mode; };
 void time_begin(sns_ctx* h, int mode);
 void time_end(sns_ctx* h);
 
+// Multi-GPU, level 0: a pass is either over every row (split 0), over the interior rows only (1: rows with a ghost
+// column, flagged in h->bnd_flag, are skipped) or over the boundary rows listed in h->bnd_rows (2).
+struct Split {
+    int mode = 0;
+    hipStream_t stream = nullptr;       // nullptr = the handle's stream
+    int partial_off = 0;
+};
+
 // y = A_l x (or fused variants).  rows = number of block rows computed.
 template <int MODE>
 void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
-                 double omega, const double* dotw) {
+                 double omega, const double* dotw, Split sp = Split()) {
+    hipStream_t st = sp.stream ? sp.stream : h->stream;
+    const bool fine = (&L == &h->levels[0]);
+    if (sp.mode == 2) rows = h->n_bnd;
     const int grid = (rows + 31) / 32;
     if (grid == 0) return;
-    const bool fine = (&L == &h->levels[0]);
-    if (fine) {
+    if (fine && sp.mode == 1) {
+        hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
+                           b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, h->bnd_flag, sp.partial_off);
+    } else if (fine && sp.mode == 2) {
+        hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 2>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
+                           b, L.dinv, omega, dotw, h->partial, h->bnd_rows, (const uint8_t*)nullptr, sp.partial_off);
+    } else if (fine) {
         time_begin(h, MODE);
-        hipLaunchKernelGGL((k_spmv<MODE, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
-                           x, y, b, L.dinv, omega, dotw, h->partial);
+        hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
+                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
         time_end(h);
     } else if constexpr (MODE != SPMV_AX_DOT) {
-        hipLaunchKernelGGL((k_spmv<MODE, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals,
-                           x, y, b, L.dinv, omega, dotw, h->partial);
+        hipLaunchKernelGGL((k_spmv<MODE, 0, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
+                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
     }
 }
 
 // Preconditioner passes (Jacobi sweep, residual) of the AMG cycle: fp32 matrix copy when enabled.
 template <int MODE>
 void launch_pc_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
-                    double omega) {
+                    double omega, Split sp = Split()) {
     if (!(h->opt.amg_f32_matrix && L.vals32)) {
-        launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr);
+        launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr, sp);
         return;
     }
+    hipStream_t st = sp.stream ? sp.stream : h->stream;
+    const bool fine = (&L == &h->levels[0]);
+    if (sp.mode == 2) rows = h->n_bnd;
     const int grid = (rows + 63) / 64;
     if (grid == 0) return;
-    if (&L == &h->levels[0]) {
+    if (fine && sp.mode == 1) {
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals32,
+                           x, y, b, L.dinv, omega, (const int32_t*)nullptr, h->bnd_flag);
+    } else if (fine && sp.mode == 2) {
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 2>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals32,
+                           x, y, b, L.dinv, omega, h->bnd_rows, (const uint8_t*)nullptr);
+    } else if (fine) {
         time_begin(h, MODE);
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
-                           L.vals32, x, y, b, L.dinv, omega);
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind,
+                           L.vals32, x, y, b, L.dinv, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
         time_end(h);
     } else {
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind,
-                           L.vals32, x, y, b, L.dinv, omega);
+        hipLaunchKernelGGL((k_spmv_f32<MODE, 0, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind,
+                           L.vals32, x, y, b, L.dinv, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
     }
+}
+
+// Level-0 pass whose input needs a halo exchange first (multi-GPU): the exchange of xe's ghost tail runs on the
+// handle's stream (every RCCL call stays on ONE stream, in program order) while the interior rows -- the rows
+// without a ghost column, i.e. nearly all of them -- are computed on a second stream; the few boundary rows follow
+// once the halo has been unpacked.  `pc` selects the preconditioner flavour of the kernel (fp32 matrix copy).
+// Without a transport, with a single rank or with SNS_NO_OVERLAP set this is exchange + one full pass.
+template <int MODE>
+int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const double* b, double omega,
+                      const double* dotw, bool pc) {
+    Level& L = h->levels[0];
+    const int32_t rows = h->n_owned;
+    Comm* c = h->comm.get();
+    const bool dist = c && c->active() && c->nranks > 1;
+    h->bnd_dot_blocks = 0;
+    auto pass = [&](Split sp) {
+        if constexpr (MODE == SPMV_B_MINUS_AX || MODE == SPMV_JACOBI) {
+            if (pc) { launch_pc_spmv<MODE>(h, L, rows, x, y, b, omega, sp); return; }
+        }
+        launch_spmv<MODE>(h, L, rows, x, y, b, omega, dotw, sp);
+    };
+    if (!dist || !h->bnd_flag || h->no_overlap) {
+        SNS_TRY(halo_exchange(h, xe));
+        pass(Split());
+        return SNS_OK;
+    }
+    const int gs = pc && h->opt.amg_f32_matrix && L.vals32 ? (rows + 63) / 64 : (rows + 31) / 32;
+    Split s1, s2;
+    s1.mode = 1;
+    s2.mode = 2;
+    s2.partial_off = gs;
+    if (MODE == SPMV_AX_DOT) h->bnd_dot_blocks = (h->n_bnd + 31) / 32;
+    if (c->nccl) {
+        if (!h->side_stream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, lo));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(h->ev_x, h->stream));                 // x (owned part) is ready
+        HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_x, 0));
+        s1.stream = h->side_stream;
+        pass(s1);                                                    // interior rows, concurrent with the halo
+        HIP_TRY(hipEventRecord(h->ev_side, h->side_stream));
+        SNS_TRY(halo_exchange(h, xe));                               // pack, ncclSend/Recv group, unpack
+        pass(s2);                                                    // boundary rows
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_side, 0));       // y complete for whatever comes next
+    } else {
+        // team transport (tests): the exchange synchronises the host anyway; same two passes, one stream
+        SNS_TRY(halo_exchange(h, xe));
+        pass(s1);
+        pass(s2);
+    }
+    return SNS_OK;
 }
 
 int alloc_level_vectors(Level& L) {
@@ -1126,8 +1220,12 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     } else if (L.xg) {      // true residual needs the neighbours' iterate
         HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        SNS_TRY(exchange_level(h, l, L.xg));
-        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
+        if (l == 0) {
+            SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, L.xg, L.xg, L.r, b, 0.0, nullptr, true));
+        } else {
+            SNS_TRY(exchange_level(h, l, L.xg));
+            launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
+        }
     } else {
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     }
@@ -1137,13 +1235,20 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
                            C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
-    if (px) {
+    int s_first = 0;
+    if (px && l == 0 && nu == 1) {
+        // the single post-smoothing sweep of the fine level with the neighbours' corrected iterate: halo of `cur`
+        // overlapped with the interior rows of the sweep
+        SNS_TRY(exchange_and_spmv<SPMV_JACOBI>(h, cur, cur, oth, b, om, nullptr, true));
+        std::swap(cur, oth);
+        s_first = 1;
+    } else if (px) {
         SNS_TRY(exchange_level(h, l, cur));
         if (ghost4 > 0 && nu > 1)
             HIP_TRY(hipMemcpyAsync(oth + 4 * (size_t)rows, cur + 4 * (size_t)rows, ghost4 * sizeof(double),
                                    hipMemcpyDeviceToDevice, h->stream));
     }
-    for (int s = 0; s < nu; ++s) {
+    for (int s = s_first; s < nu; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
@@ -1179,14 +1284,18 @@ int pc_apply(sns_ctx* h, const double* r, double* z) {
 
 // operator apply with halo exchange (x must have room for the ghost tail)
 int op_apply(sns_ctx* h, double* x, double* y) {
-    SNS_TRY(halo_exchange(h, x));
-    launch_spmv<SPMV_AX>(h, h->levels[0], h->n_owned, x, y, nullptr, 0.0, nullptr);
+    SNS_TRY(exchange_and_spmv<SPMV_AX>(h, x, x, y, nullptr, 0.0, nullptr, false));
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+// y = A x with the per-workgroup partial sums of <dotw, y> left in h->partial (BiCGStab's <rhat, A M p>)
+int op_apply_dot(sns_ctx* h, double* x, double* y, const double* dotw) {
+    SNS_TRY(exchange_and_spmv<SPMV_AX_DOT>(h, x, x, y, nullptr, 0.0, dotw, false));
     h->tm.spmv_calls++;
     return SNS_OK;
 }
 int op_residual(sns_ctx* h, double* x, const double* b, double* r) {
-    SNS_TRY(halo_exchange(h, x));
-    launch_spmv<SPMV_B_MINUS_AX>(h, h->levels[0], h->n_owned, x, r, b, 0.0, nullptr);
+    SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, x, x, r, b, 0.0, nullptr, false));
     h->tm.spmv_calls++;
     return SNS_OK;
 }
@@ -1223,7 +1332,14 @@ int dot(sns_ctx* h, const double* x, const double* y, double* out) {
     return SNS_OK;
 }
 
-// ---- BiCGStab (right-preconditioned; same recurrences as oracle/solve.py:bicgstab_bj) ----
+// ---- BiCGStab (right-preconditioned; the recurrences of oracle/solve.py:bicgstab_bj) ----
+// Latency-lean formulation: rho / alpha / omega / beta live on the device (sc[]), the vector kernels read them
+// there, and the three reductions of the textbook iteration are two -- <rhat, v>, then ONE pass for
+// (t.s, t.t, rhat.s, rhat.t, s.s), from which omega, the next rho and ||r||^2 follow (k_bicg_dots5).  The host
+// reads (||r||^2, flags) once per iteration, asynchronously: the copy is enqueued, then the x/r update and the
+// FIRST HALF of the next iteration (p, M p, A M p, <rhat, v>, alpha: none of it touches x or r) are enqueued
+// behind it, and only then does the host wait for the copy's event -- the GPU never idles on the stopping test.
+// A converged claim is confirmed by the explicitly computed ||r|| before the loop is left.
 int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
     const sns_options& o = h->opt;
     const int64_t nd = nred_of(h);
@@ -1232,59 +1348,77 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
     SNS_TRY(get_vec(h, 0, &r)); SNS_TRY(get_vec(h, 1, &rhat)); SNS_TRY(get_vec(h, 2, &p));
     SNS_TRY(get_vec(h, 3, &v)); SNS_TRY(get_vec(h, 4, &s)); SNS_TRY(get_vec(h, 5, &t));
     SNS_TRY(get_vec(h, 6, &ph)); SNS_TRY(get_vec(h, 7, &sh));
+    double* sc = h->d_scal + 128;                         // device scalar block of this solver
+    double* red = h->d_scal + 144;                        // reduction results
+    double* hpin = h->h_scal + 512;                       // pinned landing zone of (rr, flags)
+    if (!h->ev_it) HIP_TRY(hipEventCreateWithFlags(&h->ev_it, hipEventDisableTiming));
     double bnorm, rn;
     SNS_TRY(norm2(h, b, &bnorm));
     SNS_TRY(op_residual(h, x, b, r));
-    SNS_TRY(norm2(h, r, &rn));
+    // ||r0||^2 stays on the device as the first rho (rhat = r0); the host needs it for the start-up test
+    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, r, r, h->partial);
+    SNS_TRY(reduce_to(h, g, 2, red));
+    hipLaunchKernelGGL(k_bicg_init, dim3(1), dim3(64), 0, h->stream, sc, red);
+    {
+        double v0[2];
+        SNS_TRY(fetch(h, red, 2, v0));
+        rn = std::sqrt(v0[0]);
+    }
     const double tol = std::max(o.ksp_rtol * bnorm, o.ksp_atol);
     if (o.monitor) std::printf("  0 KSP Residual norm %.12e\n", rn);
     int its = 0, reason = 0;
     if (!(rn == rn)) reason = SNS_KSP_DIVERGED_NANORINF;
     else if (rn <= tol) reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL;
+    if (!reason && o.ksp_max_it < 1) reason = SNS_KSP_DIVERGED_ITS;
     if (!reason) {
         HIP_TRY(hipMemcpyAsync(rhat, r, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(v, 0, nd * sizeof(double), h->stream));
-        double rho = 1.0, alpha = 1.0, omega = 1.0;
-        double rho_new = rn * rn;                         // rhat.r with rhat = r
-        for (its = 1; its <= o.ksp_max_it; ++its) {
-            if (rho_new == 0.0) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
-            const double beta = (rho_new / rho) * (alpha / omega);
-            hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, beta, omega, v, p);
+        auto first_half = [&]() -> int {                  // p, ph = M p, v = A ph, alpha
+            hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, p);
             SNS_TRY(pc_apply(h, p, ph));
-            SNS_TRY(halo_exchange(h, ph));
-            {   // v = A ph, fused rhat.v
-                const int32_t rows = h->n_owned;
-                const int gs = (rows + 31) / 32;
-                launch_spmv<SPMV_AX_DOT>(h, h->levels[0], rows, ph, v, nullptr, 0.0, rhat);
-                h->tm.spmv_calls++;
-                SNS_TRY(reduce_to(h, gs, 1, h->d_scal));
-            }
-            double rv;
-            SNS_TRY(fetch(h, h->d_scal, 1, &rv));
-            alpha = rho_new / rv;
-            hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, alpha, v, s, h->partial);
+            const int32_t rows = h->n_owned;
+            const int gs = (rows + 31) / 32;
+            SNS_TRY(op_apply_dot(h, ph, v, rhat));        // v = A ph with the fused partial sums of <rhat, v>
+            SNS_TRY(reduce_to(h, gs + h->bnd_dot_blocks, 1, red));
+            hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
+            return SNS_OK;
+        };
+        SNS_TRY(first_half());
+        for (its = 1;; ++its) {
+            hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
             SNS_TRY(pc_apply(h, s, sh));
             SNS_TRY(op_apply(h, sh, t));
-            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, s, t, h->partial);
-            SNS_TRY(reduce_to(h, g, 2, h->d_scal));
-            double ts[2];
-            SNS_TRY(fetch(h, h->d_scal, 2, ts));
-            omega = (ts[1] > 0.0) ? ts[0] / ts[1] : 0.0;
-            hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, alpha, ph, omega, sh, s, t, rhat, x,
-                               r, h->partial);
-            SNS_TRY(reduce_to(h, g, 2, h->d_scal));
-            double rr[2];
-            SNS_TRY(fetch(h, h->d_scal, 2, rr));
-            rho = rho_new;
-            rho_new = rr[0];
-            rn = std::sqrt(rr[1]);
+            hipLaunchKernelGGL(k_bicg_dots5, dim3(g), dim3(256), 0, h->stream, nd, s, t, rhat, h->partial);
+            SNS_TRY(reduce_to(h, g, 5, red));
+            hipLaunchKernelGGL(k_bicg_omega, dim3(1), dim3(64), 0, h->stream, sc, red);
+            HIP_TRY(hipMemcpyAsync(hpin, sc + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipEventRecord(h->ev_it, h->stream));
+            hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, x, r);
+            // speculative first half of the next iteration, enqueued BEFORE the host looks at this one's result
+            const bool spec = its < o.ksp_max_it;
+            if (spec) SNS_TRY(first_half());
+            HIP_TRY(hipEventSynchronize(h->ev_it));
+            ++h->ctr_host_syncs;
+            const double rr = hpin[0];
+            const int flags = (int)hpin[1];
+            rn = std::sqrt(rr);
             if (o.monitor) std::printf("%3d KSP Residual norm %.12e\n", its, rn);
-            if (!(rn == rn) || std::isinf(rn)) { reason = SNS_KSP_DIVERGED_NANORINF; break; }
-            if (rn <= tol) { reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL; break; }
-            if (omega == 0.0) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+            if ((flags & 1) || !(rn == rn) || std::isinf(rn)) { reason = SNS_KSP_DIVERGED_NANORINF; break; }
+            if (rn <= tol) {
+                // the three-term formula can lose digits when ||r|| << ||s||: confirm with the vector itself
+                double rtrue;
+                SNS_TRY(norm2(h, r, &rtrue));
+                if (rtrue <= tol) {
+                    rn = rtrue;
+                    reason = (rn <= o.ksp_atol) ? SNS_KSP_CONVERGED_ATOL : SNS_KSP_CONVERGED_RTOL;
+                    break;
+                }
+            }
+            if (flags & 2) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+            if (its >= o.ksp_max_it) { reason = SNS_KSP_DIVERGED_ITS; break; }
+            if (flags & 4) { reason = SNS_KSP_DIVERGED_BREAKDOWN; ++its; break; }   // rho == 0 stops the NEXT iteration
         }
-        if (!reason) { reason = SNS_KSP_DIVERGED_ITS; its = o.ksp_max_it; }
     }
     *its_out = its;
     *reason_out = reason;
@@ -1505,6 +1639,7 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
 int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double* rnorm) {
     if (!h->has_matrix) { set_error("krylov_solve before a matrix was assembled"); return SNS_E_STATE; }
     if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
+    h->ctr_host_syncs = h->ctr_allreduce = h->ctr_exchange = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     int rc;
     if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
@@ -1512,6 +1647,7 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     else if (h->opt.ksp_type == SNS_KSP_TFQMR) rc = tfqmr(h, b, x, its, reason, rnorm);
     else { set_error("bad ksp_type"); return SNS_E_ARG; }
     SNS_TRY(rc);
+    h->last_ctr[0] = h->ctr_host_syncs; h->last_ctr[1] = h->ctr_allreduce; h->last_ctr[2] = h->ctr_exchange;
     SNS_TRY(halo_exchange(h, x));                          // leave the solution's ghost tail current
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1697,7 +1833,7 @@ static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_te
         SNS_TRY(dev_upload(&h->levels[0].free_mask, fm, nullptr));
     }
     // per-block partial sums: vector kernels use <= 2048 blocks x <= 8 sums, the fused SpMV+dot one block per 32 rows
-    SNS_TRY(dev_alloc(&h->partial, std::max<size_t>((size_t)65536 * 8, (size_t)n_nodes / 32 + 64)));
+    SNS_TRY(dev_alloc(&h->partial, std::max<size_t>((size_t)65536 * 8, (size_t)n_nodes / 16 + 128)));
     SNS_TRY(dev_alloc(&h->partial2, (size_t)4096 * 8));
     SNS_TRY(dev_alloc(&h->d_scal, 256));
     SNS_TRY(dev_alloc(&h->d_sing, 1));
@@ -1761,6 +1897,11 @@ int sns_destroy(sns_handle h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_it) (void)hipEventDestroy(h->ev_it);
+    fr(h->bnd_rows); fr(h->bnd_flag);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_x) (void)hipEventDestroy(h->ev_x);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     fr(h->cg_colmap); fr(h->cg_rows); fr(h->cg_full); fr(h->cg_send); fr(h->cg_recv);
     for (auto& L : h->levels) fr(L.xg);
     if (h->comm) {
@@ -1863,6 +2004,20 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     p.h_send_idx.assign(send_idx, send_idx + ns);
     p.h_recv_idx.assign(recv_idx, recv_idx + nr);
     SNS_TRY(plan_upload(p));
+    {
+        // owned rows that reference a ghost column: the only rows of a level-0 pass that must wait for the halo
+        const HostPattern& P = *h->pattern;
+        std::vector<int32_t> rows((size_t)std::max(1, n_owned), 0);
+        std::vector<uint8_t> flag((size_t)std::max(1, n_owned), 0);
+        int32_t nb = 0;
+        SNS_TRY(sns_host_boundary_rows(n_owned, P.rowptr.data(), P.colind.data(), rows.data(), &nb));
+        for (int32_t q = 0; q < nb; ++q) flag[rows[q]] = 1;
+        h->n_bnd = nb;
+        rows.resize((size_t)std::max(1, nb));
+        SNS_TRY(dev_upload(&h->bnd_rows, rows, nullptr));
+        SNS_TRY(dev_upload(&h->bnd_flag, flag, nullptr));
+        h->no_overlap = std::getenv("SNS_NO_OVERLAP") != nullptr;
+    }
     if (!c.active()) {
         // no transport: the per-rank hierarchy must not reference ghost dofs at all
         std::vector<uint8_t> fm((size_t)4 * h->n);
@@ -2085,6 +2240,14 @@ int sns_export(sns_handle h, int what, void* dst, int64_t nbytes) {
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)need, hipMemcpyDeviceToDevice, h->stream));
     return sync_stream(h);
 }
+int sns_get_counters(sns_handle h, int64_t out[4]) {
+    if (!h || !out) return SNS_E_ARG;
+    out[0] = h->last_ctr[0];
+    out[1] = h->last_ctr[1];
+    out[2] = h->last_ctr[2];
+    out[3] = h->tm.ksp_its;
+    return SNS_OK;
+}
 int sns_get_timings(sns_handle h, sns_timings* t) {
     if (!h || !t) return SNS_E_ARG;
     *t = h->tm;
@@ -2142,22 +2305,22 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
                 if (which >= 10) {                // f32 Jacobi: production vs production with (which-10) KiB of unused
                                                   // dynamic LDS per workgroup, i.e. fewer resident waves per CU
                     const int grid = (rows + 63) / 64;
-                    hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0>), dim3(grid), dim3(256), v ? (size_t)(which - 10) * 1024 : 0,
-                                       h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                    hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0, 0>), dim3(grid), dim3(256), v ? (size_t)(which - 10) * 1024 : 0,
+                                       h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
                 } else if (which == 3) {          // fp64 y = Ax: production (nt, cooperative loads) vs the r1e loop
                     const int grid = (rows + 31) / 32;
-                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
-                    else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
+                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                    else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                 } else if (which == 0) {
                     const int grid = (rows + 31) / 32;
-                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
-                    else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial);
+                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                    else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                 } else {
                     const int grid = (rows + 63) / 64;
                     // which = 1: production vs variant 1; which = 2: production vs variant 2
-                    if (v && which == 1) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
-                    else if (v) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
-                    else hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7);
+                    if (v && which == 1) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+                    else if (v) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+                    else hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
                 }
             }
             HIP_TRY(hipEventRecord(h->ev1, h->stream));

@@ -276,3 +276,16 @@ extern "C" int sns_host_aggregate(int32_t n, const int32_t* rowptr, const int32_
     if (n_agg_out) *n_agg_out = nc;
     return SNS_OK;
 }
+
+// owned rows (i < n_owned) of a local pattern with at least one ghost column (>= n_owned): the boundary rows of
+// the interior / boundary split of the multi-GPU SpMV (the interior rows never wait for the halo)
+extern "C" int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind, int32_t* rows_out,
+                                      int32_t* n_out) {
+    if (n_owned < 0 || !rowptr || !colind || !rows_out || !n_out) { sns::set_error("sns_host_boundary_rows: bad arguments"); return SNS_E_ARG; }
+    int32_t m = 0;
+    for (int32_t i = 0; i < n_owned; ++i)
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            if (colind[k] >= n_owned) { rows_out[m++] = i; break; }
+    *n_out = m;
+    return SNS_OK;
+}

@@ -48,13 +48,15 @@ __global__ void k_gather_matrix(int64_t nnzb, const int64_t* c_ptr, const int32_
 __global__ void k_gather_residual(int32_t n_rows, const int64_t* nt_ptr, const int32_t* nt_idx,
                                   const uint8_t* bc_mask, const double* bc_val, const double* w, const double* Fe,
                                   double* F);
-template <int MODE, int FINE, int NT>
+template <int MODE, int FINE, int NT, int SPLIT>
 __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
-                       const double* dotw, double* partial);
-template <int MODE, int FINE, int VAR>
+                       const double* dotw, double* partial, const int32_t* row_list, const uint8_t* skip,
+                       int partial_off);
+template <int MODE, int FINE, int VAR, int SPLIT>
 __global__ void k_spmv_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const float* vals,
-                           const double* x, double* y, const double* bvec, const double* dinv, double omega);
+                           const double* x, double* y, const double* bvec, const double* dinv, double omega,
+                           const int32_t* row_list, const uint8_t* skip);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
@@ -63,11 +65,14 @@ __global__ void k_reduce_chunks(int nblocks, int nred, const double* partial, do
 __global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);
 __global__ void k_axpby(int64_t n, double a, const double* x, double b, double* y);
 __global__ void k_axpbypcz(int64_t n, double a, const double* x, double b, const double* y, double c, double* z);
-__global__ void k_bicg_p(int64_t n, const double* r, double beta, double omega, const double* v, double* p);
-__global__ void k_bicg_s(int64_t n, const double* r, double alpha, const double* v, double* s, double* partial);
-__global__ void k_bicg_xr(int64_t n, double alpha, const double* ph, double omega, const double* sh,
-                          const double* s, const double* t, const double* rhat, double* x, double* r,
-                          double* partial);
+__global__ void k_bicg_p(int64_t n, const double* r, const double* sc, const double* v, double* p);
+__global__ void k_bicg_alpha(double* sc, const double* red);
+__global__ void k_bicg_s(int64_t n, const double* r, const double* sc, const double* v, double* s);
+__global__ void k_bicg_dots5(int64_t n, const double* s, const double* t, const double* rhat, double* partial);
+__global__ void k_bicg_omega(double* sc, const double* red);
+__global__ void k_bicg_xr(int64_t n, const double* sc, const double* ph, const double* sh, const double* s,
+                          const double* t, double* x, double* r);
+__global__ void k_bicg_init(double* sc, const double* rr0);
 __global__ void k_multi_dot8(int64_t n, int nv, const double* V, int64_t ldv, const double* w, double* partial);
 __global__ void k_multi_axpy8(int64_t n, int nv, const double* V, int64_t ldv, const double* h, double sign,
                               double* w, double* partial);

@@ -1308,21 +1308,29 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 
 // FINE only tags the instantiation launched on the assembled (level-0) operator so that
 // profiler summaries separate it from the small coarse-level launches.
-template <int MODE, int FINE, int NT>
+// SPLIT (multi-GPU, level 0): 0 = every row; 1 = interior pass: rows flagged in `skip` (rows with a ghost column)
+// are left alone, so the pass can run while the halo is still in flight; 2 = boundary pass over the n_rows rows
+// listed in `row_list`, after the halo has arrived.  partial_off: first partial-sum slot of this launch (AX_DOT).
+template <int MODE, int FINE, int NT, int SPLIT>
 __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                               const int32_t* __restrict__ colind,
                                               const double* __restrict__ vals, const double* __restrict__ x,
                                               double* __restrict__ y, const double* __restrict__ bvec,
                                               const double* __restrict__ dinv, double omega,
-                                              const double* __restrict__ dotw, double* __restrict__ partial) {
+                                              const double* __restrict__ dotw, double* __restrict__ partial,
+                                              const int32_t* __restrict__ row_list,
+                                              const uint8_t* __restrict__ skip, int partial_off) {
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int t = lane & 7;
     const int r = t >> 1, hf = t & 1;
-    const int32_t row = (blk * 4 + (tid >> 6)) * 8 + (lane >> 3);
+    const int32_t ridx = (blk * 4 + (tid >> 6)) * 8 + (lane >> 3);
     double acc0 = 0.0, acc1 = 0.0;
-    const bool live = row < n_rows;
+    bool live = ridx < n_rows;
+    int32_t row = ridx;
+    if (SPLIT == 2) row = live ? row_list[ridx] : 0;
+    if (SPLIT == 1) live = live && !skip[ridx];
     // per-row operands of the epilogue are requested before the block loop (their latency hides behind it)
     double pre_v = 0.0, pre_x = 0.0;
     if (live && hf == 0) {
@@ -1407,22 +1415,31 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
         for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
         if (lane == 0) red[tid >> 6] = pr;
         __syncthreads();
-        if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0) partial[blockIdx.x + partial_off] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
-#define SNS_INST_SPMV(M, F, N)                                                                                  \
-    template __global__ void k_spmv<M, F, N>(int32_t, const int32_t*, const int32_t*, const double*, const double*, \
-                                             double*, const double*, const double*, double, const double*, double*);
-SNS_INST_SPMV(SPMV_AX, 1, 1)
-SNS_INST_SPMV(SPMV_AX, 1, 0)
-SNS_INST_SPMV(SPMV_AX, 1, 2)
-SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1)
-SNS_INST_SPMV(SPMV_JACOBI, 1, 1)
-SNS_INST_SPMV(SPMV_AX_DOT, 1, 1)
-SNS_INST_SPMV(SPMV_AX, 0, 0)
-SNS_INST_SPMV(SPMV_B_MINUS_AX, 0, 0)
-SNS_INST_SPMV(SPMV_JACOBI, 0, 0)
+#define SNS_INST_SPMV(M, F, N, S)                                                                                  \
+    template __global__ void k_spmv<M, F, N, S>(int32_t, const int32_t*, const int32_t*, const double*, const double*, \
+                                                double*, const double*, const double*, double, const double*, double*, \
+                                                const int32_t*, const uint8_t*, int);
+SNS_INST_SPMV(SPMV_AX, 1, 1, 0)
+SNS_INST_SPMV(SPMV_AX, 1, 0, 0)
+SNS_INST_SPMV(SPMV_AX, 1, 2, 0)
+SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1, 0)
+SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 0)
+SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 0)
+SNS_INST_SPMV(SPMV_AX, 0, 0, 0)
+SNS_INST_SPMV(SPMV_B_MINUS_AX, 0, 0, 0)
+SNS_INST_SPMV(SPMV_JACOBI, 0, 0, 0)
+SNS_INST_SPMV(SPMV_AX, 1, 1, 1)
+SNS_INST_SPMV(SPMV_AX, 1, 1, 2)
+SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1, 1)
+SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1, 2)
+SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 1)
+SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 2)
+SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 1)
+SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 2)
 
 // Preconditioner passes with fp32 MATRIX VALUES (vectors, D^-1 and all arithmetic stay fp64):
 // the smoother / residual passes of the AMG cycle read a rounded copy of each level operator,
@@ -1435,18 +1452,23 @@ template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true); }
 
 // VAR: 0 = production; 1, 2 = variants kept for the interleaved A/B harness (sns_bench_variants)
-template <int MODE, int FINE, int VAR>
+template <int MODE, int FINE, int VAR, int SPLIT>
 __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colind,
                                                   const float* __restrict__ vals, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ bvec,
-                                                  const double* __restrict__ dinv, double omega) {
+                                                  const double* __restrict__ dinv, double omega,
+                                                  const int32_t* __restrict__ row_list,
+                                                  const uint8_t* __restrict__ skip) {
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = lane & 3;
-    const int32_t row = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
-    const bool live = row < n_rows;
+    const int32_t ridx = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    bool live = ridx < n_rows;
+    int32_t row = ridx;
+    if (SPLIT == 2) row = live ? row_list[ridx] : 0;
+    if (SPLIT == 1) live = live && !skip[ridx];
     double acc0 = 0.0, acc1 = 0.0;
     // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
@@ -1514,15 +1536,20 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
             y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
     }
 }
-#define SNS_INST_SPMV32(M, F, N)                                                                              \
-    template __global__ void k_spmv_f32<M, F, N>(int32_t, const int32_t*, const int32_t*, const float*,         \
-                                                 const double*, double*, const double*, const double*, double);
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 1)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 2)
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 0, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 0, 0)
+#define SNS_INST_SPMV32(M, F, N, S)                                                                              \
+    template __global__ void k_spmv_f32<M, F, N, S>(int32_t, const int32_t*, const int32_t*, const float*,         \
+                                                    const double*, double*, const double*, const double*, double,  \
+                                                    const int32_t*, const uint8_t*);
+SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 0)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 0)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 1, 0)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 2, 0)
+SNS_INST_SPMV32(SPMV_B_MINUS_AX, 0, 0, 0)
+SNS_INST_SPMV32(SPMV_JACOBI, 0, 0, 0)
+SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 1)
+SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 2)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 1)
+SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 2)
 
 __global__ __launch_bounds__(256) void k_cvt_f32(int64_t n, const double* __restrict__ x, float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -1700,41 +1727,81 @@ __global__ __launch_bounds__(256) void k_axpbypcz(int64_t n, double a, const dou
         z[i] = a * x[i] + b * y[i] + (c == 0.0 ? 0.0 : c * z[i]);
 }
 
-// BiCGStab: p = r + beta * (p - omega * v)
-__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* __restrict__ r, double beta, double omega,
+// ---- BiCGStab with device-resident scalars ------------------------------------------------------------------
+// sc[0] = rho = <rhat, r>, sc[1] = alpha, sc[2] = omega, sc[3] = beta, sc[4] = ||r||^2, sc[5] = flags
+// (1: NaN/Inf, 2: omega == 0, 4: rho == 0), sc[6] = <rhat, v>.  The host never needs them to launch the next kernel:
+// it reads (sc[4], sc[5]) once per iteration, asynchronously, for the stopping test only.
+// p = r + beta * (p - omega * v)
+__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* __restrict__ r, const double* __restrict__ sc,
                                                 const double* __restrict__ v, double* __restrict__ p) {
+    const double beta = sc[3], omega = sc[2];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = r[i] + beta * (p[i] - omega * v[i]);
 }
-
-// BiCGStab: s = r - alpha v ; partial = (s.s)
-__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restrict__ r, double alpha,
-                                                const double* __restrict__ v, double* __restrict__ s,
-                                                double* __restrict__ partial) {
-    double acc[1] = {0.0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double sv = r[i] - alpha * v[i];
-        s[i] = sv;
-        acc[0] += sv * sv;
+// alpha = rho / <rhat, v>
+__global__ void k_bicg_alpha(double* __restrict__ sc, const double* __restrict__ red) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sc[6] = red[0];
+        sc[1] = sc[0] / red[0];
     }
-    block_reduce_store<1>(acc, partial);
 }
-
-// BiCGStab: x += alpha ph + omega sh ; r = s - omega t ; partial = (rhat.r, r.r)
-__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, double alpha, const double* __restrict__ ph,
-                                                 double omega, const double* __restrict__ sh,
-                                                 const double* __restrict__ s, const double* __restrict__ t,
-                                                 const double* __restrict__ rhat, double* __restrict__ x,
-                                                 double* __restrict__ r, double* __restrict__ partial) {
-    double acc[2] = {0.0, 0.0};
+// s = r - alpha v
+__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restrict__ r, const double* __restrict__ sc,
+                                                const double* __restrict__ v, double* __restrict__ s) {
+    const double alpha = sc[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s[i] = r[i] - alpha * v[i];
+}
+// ONE reduction pass for the second half of an iteration: (t.s, t.t, rhat.s, rhat.t, s.s).  omega = t.s / t.t, and
+// with r = s - omega t the next rho and the new residual norm follow without touching r:
+//   <rhat, r> = rhat.s - omega rhat.t,   ||r||^2 = s.s - 2 omega t.s + omega^2 t.t
+__global__ __launch_bounds__(256) void k_bicg_dots5(int64_t n, const double* __restrict__ s, const double* __restrict__ t,
+                                                    const double* __restrict__ rhat, double* __restrict__ partial) {
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double sv = s[i], tv = t[i], hv = rhat[i];
+        acc[0] += tv * sv;
+        acc[1] += tv * tv;
+        acc[2] += hv * sv;
+        acc[3] += hv * tv;
+        acc[4] += sv * sv;
+    }
+    block_reduce_store<5>(acc, partial);
+}
+// omega, next rho, beta of the NEXT iteration, ||r||^2 and the flags; out[0..1] = (||r||^2, flags) for the host
+__global__ void k_bicg_omega(double* __restrict__ sc, const double* __restrict__ red) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ts = red[0], tt = red[1], hs = red[2], ht = red[3], ss = red[4];
+    const double omega = (tt > 0.0) ? ts / tt : 0.0;
+    const double rho_new = hs - omega * ht;
+    double rr = ss - 2.0 * omega * ts + omega * omega * tt;
+    const double rho = sc[0], alpha = sc[1];
+    double flags = 0.0;
+    if (!(rr == rr) || isinf(rr) || !(alpha == alpha)) flags += 1.0;
+    if (rr < 0.0) rr = 0.0;                             // round-off of the three-term formula
+    if (omega == 0.0) flags += 2.0;
+    if (rho_new == 0.0) flags += 4.0;
+    sc[3] = (rho_new / rho) * (alpha / omega);
+    sc[0] = rho_new;
+    sc[2] = omega;
+    sc[4] = rr;
+    sc[5] = flags;
+}
+// x += alpha ph + omega sh ; r = s - omega t
+__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __restrict__ sc, const double* __restrict__ ph,
+                                                 const double* __restrict__ sh, const double* __restrict__ s,
+                                                 const double* __restrict__ t, double* __restrict__ x,
+                                                 double* __restrict__ r) {
+    const double alpha = sc[1], omega = sc[2];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         x[i] += alpha * ph[i] + omega * sh[i];
-        const double rv = s[i] - omega * t[i];
-        r[i] = rv;
-        acc[0] += rhat[i] * rv;
-        acc[1] += rv * rv;
+        r[i] = s[i] - omega * t[i];
     }
-    block_reduce_store<2>(acc, partial);
+}
+// sc[0..7] = (rho, alpha, omega, beta, rr, flags, 0, 0) at the start of a solve: rho = rr0 (rhat = r), beta = 0
+__global__ void k_bicg_init(double* __restrict__ sc, const double* __restrict__ rr0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    sc[0] = rr0[0]; sc[1] = 1.0; sc[2] = 1.0; sc[3] = 0.0; sc[4] = rr0[0]; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
 }
 
 // GMRES: h[k] = V_k . w for k < nv (chunks of 8 basis vectors per pass over w)

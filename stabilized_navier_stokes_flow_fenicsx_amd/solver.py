@@ -316,6 +316,12 @@ class FlowProblem:
         check(self.lib.sns_get_timings(self.h, C.byref(t)))
         return t
 
+    def counters(self):
+        """Debug counters of the last Krylov solve: host syncs, all-reduces, halo exchanges (+ ksp its since reset)."""
+        c = (C.c_int64 * 4)()
+        check(self.lib.sns_get_counters(self.h, c))
+        return dict(host_syncs=c[0], allreduces=c[1], exchanges=c[2], ksp_its=c[3])
+
     def reset_timings(self):
         check(self.lib.sns_reset_timings(self.h))
 

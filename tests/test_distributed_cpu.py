@@ -56,6 +56,21 @@ def _worker(rank, world, port, kind, q):
         err_halo = np.abs(xt.numpy() - x[gdof]).max()
         yl = Jl[:no] @ xt.numpy()
         err_spmv = np.abs(yl - (Jg @ x)[gdof[:no]]).max()
+        # interior / boundary split of the multi-GPU SpMV (exchange_and_spmv in csrc/sns_api.hip): rows without a
+        # ghost column are computed from the OWNED part of x alone, i.e. before the halo has arrived; only the rows
+        # sns_host_boundary_rows lists wait for it
+        from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+        rp, ci, _, _ = _lib.host_pattern(part.n_local, part.mesh.tets)
+        bnd = _lib.host_boundary_rows(part.n_owned, rp, ci)
+        interior = np.setdiff1d(np.arange(part.n_owned), bnd)
+        x_owned_only = xl.copy()                                    # ghost tail still zero: no exchange yet
+        di = (4 * interior[:, None] + np.arange(4)[None]).ravel()
+        db = (4 * bnd[:, None] + np.arange(4)[None]).ravel()
+        y_split = np.zeros(no)
+        y_split[di] = Jl[di] @ x_owned_only
+        y_split[db] = Jl[db] @ xt.numpy()                           # after the exchange
+        err_split = np.abs(y_split - (Jg @ x)[gdof[:no]]).max()
+        n_bnd = len(bnd)
         d = torch.tensor([float(xl[:no] @ xl[:no])], dtype=torch.float64)
         dist.all_reduce(d)
         err_dot = abs(float(d) - float(x @ x)) / float(x @ x)
@@ -80,30 +95,46 @@ def _worker(rank, world, port, kind, q):
             dist.all_reduce(t)
             return float(t)
 
+        def gdots(*pairs):                                          # ONE all-reduce for several dots
+            t = torch.tensor([float(a @ b) for a, b in pairs], dtype=torch.float64)
+            dist.all_reduce(t)
+            n_allreduce[0] += 1
+            return t.numpy()
+
+        # the product's latency-lean BiCGStab (csrc/sns_api.hip:bicgstab): TWO all-reduces per iteration --
+        # <rhat, v>, then (t.s, t.t, rhat.s, rhat.t, s.s) from which omega, the next rho and ||r||^2 follow
+        n_allreduce = [0]
         xk = np.zeros(no)
         r = bl - Av(xk)
         rhat = r.copy()
-        rho = alpha = omega = 1.0
+        rho, bb = gdots((rhat, r), (bl, bl))
+        bn = np.sqrt(bb)
+        n_allreduce[0] = 0
+        beta = 0.0
+        omega = 1.0
         v = np.zeros(no)
         p = np.zeros(no)
-        bn = np.sqrt(gdot(bl, bl))
         its = 0
         for its in range(1, 400):
-            rho_new = gdot(rhat, r)
-            beta = (rho_new / rho) * (alpha / omega)
             p = r + beta * (p - omega * v)
             ph = Mv(p)
             v = Av(ph)
-            alpha = rho_new / gdot(rhat, v)
+            alpha = rho / gdots((rhat, v))[0]
             s = r - alpha * v
             sh = Mv(s)
             t = Av(sh)
-            omega = gdot(t, s) / gdot(t, t)
+            ts, tt, hs, ht, ss = gdots((t, s), (t, t), (rhat, s), (rhat, t), (s, s))
+            omega = ts / tt
+            rho_new = hs - omega * ht
+            rr = ss - 2 * omega * ts + omega * omega * tt
             xk = xk + alpha * ph + omega * sh
             r = s - omega * t
+            beta = (rho_new / rho) * (alpha / omega)
             rho = rho_new
-            if np.sqrt(gdot(r, r)) <= 1e-10 * bn:
+            if np.sqrt(max(rr, 0.0)) <= 1e-10 * bn:
                 break
+        allreduce_per_it = n_allreduce[0] / its
+        err_rr = abs(np.sqrt(max(rr, 0.0)) - np.sqrt(gdot(r, r))) / bn
         Ug = S.lu_solve(Ag, bg)
         err_sol = np.abs(xk - Ug[gdof[:no]]).max() / np.abs(Ug).max()
         xo, its_serial, _ = S.bicgstab_bj(Ag, bg, rtol=1e-10)
@@ -112,6 +143,7 @@ def _worker(rank, world, port, kind, q):
         err_gather = np.abs(full.numpy() - w).max()
         q.put((rank, dict(err_rows=err_rows, err_F=err_F, err_halo=err_halo, err_spmv=err_spmv, err_dot=err_dot,
                           err_sol=err_sol, its=its, its_serial=its_serial, err_gather=err_gather,
+                          err_split=err_split, n_bnd=n_bnd, allreduce_per_it=allreduce_per_it, err_rr=err_rr,
                           n_owned=part.n_owned, n_local=part.n_local, nbr=list(map(int, part.neighbors)))))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
@@ -138,6 +170,8 @@ def test_partition_halo_and_distributed_krylov_gloo(world, kind):
         assert out["err_halo"] == 0.0 and out["err_spmv"] < 1e-12 and out["err_dot"] < 1e-13
         assert out["err_sol"] < 1e-6 and abs(out["its"] - out["its_serial"]) <= 3
         assert out["err_gather"] == 0.0
+        assert out["err_split"] < 1e-12 and 0 < out["n_bnd"] < out["n_owned"]    # interior rows need no halo
+        assert out["allreduce_per_it"] == 2.0 and out["err_rr"] < 1e-12          # merged reductions, same residual
         assert out["n_local"] > out["n_owned"] and len(out["nbr"]) >= 1
         tot_owned += out["n_owned"]
     n_nodes = (9 * 4 * 4) if kind == "duct" else 6 ** 3

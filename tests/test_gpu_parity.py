@@ -169,6 +169,23 @@ def test_stokes_solve_vs_lu(gpu, ksp, pc):
     P.close()
 
 
+def test_bicgstab_needs_one_host_sync_per_iteration(gpu):
+    """The stopping test is the only thing the host reads inside the BiCGStab loop, and it reads it asynchronously
+    (sns_get_counters): iterations + a constant (norms of b and r0, the confirmation of the converged residual)."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((24, 8, 8), 4.0)
+    P = gpu(m, B.duct_bcs(m), reynolds=30.0, monitor=0)
+    U, res = P.stokes_solve()
+    c = P.counters()
+    assert res.reason > 0 and res.its >= 5
+    assert c["host_syncs"] <= res.its + 4, (c, res.its)
+    assert c["allreduces"] == 0 and c["exchanges"] == 0                    # single GPU: no communicator
+    P.set_options(snes_max_it=1)
+    w, n = P.newton_solve(U.clone())
+    assert P.counters()["host_syncs"] <= n.ksp_its + 4
+    P.close()
+
+
 def test_bicgstab_iteration_history_matches_oracle(gpu):
     """Same algorithm, same preconditioner => same iteration count as oracle.bicgstab_bj."""
     from oracle import assemble as asm, solve as S
@@ -442,15 +459,23 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
             part = PT.build_local_part(m, mask, g, owner, rank, nranks)
             P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team, **kw)
         U, r = P.stokes_solve()
+        # latency structure of the Krylov loop: at most ONE host synchronisation per BiCGStab iteration inside the
+        # loop (the asynchronous stopping test) and two all-reduces per iteration on the Krylov level -- the V-cycle
+        # adds none (its smoothing is rank-local, the replicated tail uses all-gathers)
+        c = P.counters()
+        sizes = P.sizes()
         w, n = P.newton_solve(U.clone())
-        out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n, P.timings().amg_levels)
+        out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n, P.timings().amg_levels, c, sizes)
         P.close()
         return out
 
     outs = team.run(work)
     team.close()
     Ug, wg = np.zeros(m.num_dofs), np.zeros(m.num_dofs)
-    for part, U, r, w, n, nlev in outs:
+    for part, U, r, w, n, nlev, ctr, _sz in outs:
+        if not isinstance(team, type(None)) and kind != "slab":
+            # the team transport itself synchronises inside every collective; count what the solver asked for
+            assert ctr["allreduces"] <= 2 * r.its + 6, (ctr, r.its)
         gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
         Ug[gd], wg[gd] = U[:4 * part.n_owned], w[:4 * part.n_owned]
         assert r.reason > 0 and n.reason == ns.reason and n.its == ns.its
