@@ -10,9 +10,12 @@ When the sequence converges (||F|| < 1e-8, :281) it restarts from the Stokes sol
 metric = M-DOF/s = N_dof / (t_assemble + t_solve) per Newton iteration / 1e6  (SURVEY 8d).
 
   python bench.py [--gpus N --steps K --warmup W]           (N>1 under torch.distributed.run)
-N>1 (weak scaling): the duct is refined by N^(1/3) per direction, every GPU keeps a ~10.1 M-tet x-slab
-(--strong: the SAME mesh is element-partitioned over the ranks instead), halo exchange
-and dot-product all-reduces on RCCL inside libsns.so.
+N>1: the HEADLINE is what north_star states -- the SAME 10.1 M-tet duct element-partitioned into N x-slabs (strong
+scaling; every rank meshes only its own slab), halo exchange and dot-product all-reduces on RCCL inside libsns.so.
+The weak layout (duct refined by N^(1/3) per direction, every GPU keeps a ~10.1 M-tet slab) is timed afterwards and
+reported under "weak_scaling" in the same JSON line (--no-weak skips it).
+--config 3 / 4 time the other full-size BASELINE configs (55^3 cavity Re 100; 240x60x60 two-stream channel) as
+secondary lines; the default (5) is the headline.
 """
 import argparse
 import glob
@@ -37,38 +40,39 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(sample_cells=(140, 35, 35), re_full=200.0, full_ny=75):
-    """The oracle's C/OpenMP restatement ("port", oracle/c) timed on the host cores on a bounded
-    sample of the same workload: ONE Newton iteration (assemble J+F, solve to rtol 1e-8) on the
-    ~1 M-tet duct at the same cell Reynolds number Re*h as the full run, with the REFERENCE's
-    linear algorithm: KSP tfqmr (NavierStokesChannelFlow.py:77,282-283) + PETSc's default
-    preconditioner, block-Jacobi (one block per thread) with ILU(0) on each block."""
+def cpu_baseline(mesh, mask, g, U, Re, maxit=200):
+    """The oracle's C/OpenMP restatement ("port", oracle/c) timed on the host cores on THE SAME workload as the GPU
+    line (same mesh, BCs, initial guess, tolerances): ONE Newton iteration at the Stokes solution U
+    of the full mesh -- assemble J+F, solve J y = F to rtol 1e-8, line-search residual -- with the REFERENCE's linear
+    algorithm: KSP tfqmr (NavierStokesChannelFlow.py:77,282-283) + PETSc's default preconditioner in parallel,
+    block-Jacobi (one block per thread) with ILU(0) on each block.  The Krylov solve is bounded by `maxit`
+    iterations so that the default bench run stays within minutes; if it stops there the rate is an UPPER bound
+    for the CPU and the sample text says so."""
     from oracle import cport
-    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
-    m = M.duct_mesh(sample_cells, 4.0)
-    mask, g = B.duct_bcs(m).flatten()
-    Re = re_full * sample_cells[1] / full_ny
     # one GPU's host share is 16 cores on the bench box; the reference's own runs use 6 ranks (run_all_images.sh:6)
     cport.set_num_threads(min(16, os.cpu_count() or 1, cport.num_threads()))
     nthr = cport.num_threads()
-    print(f"[bench] cpu_baseline: {m.num_tets} tets on {nthr} threads", file=sys.stderr, flush=True)
-    rp, ci = cport.pattern(m.num_nodes, m.tets)
-    vals, F0 = cport.assemble("stokes", m.points, m.tets, None, 1.0, mask, g, rp, ci)
-    U, sits, sreason, _ = cport.solve(m.num_nodes, rp, ci, vals, -F0, method="tfqmr", pc="ilu0", rtol=1e-8, maxit=2000)
-    print(f"[bench] cpu_baseline: Stokes presolve {sits} its reason {sreason}", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: {mesh.num_tets} tets on {nthr} threads", file=sys.stderr, flush=True)
+    rp, ci = cport.pattern(mesh.num_nodes, mesh.tets)
     t0 = time.time()
-    vals, F = cport.assemble("ns", m.points, m.tets, U, Re, mask, g, rp, ci)
+    vals, F = cport.assemble("ns", mesh.points, mesh.tets, U, Re, mask, g, rp, ci)
     t1 = time.time()
-    y, its, reason, rn = cport.solve(m.num_nodes, rp, ci, vals, F, method="tfqmr", pc="ilu0", rtol=1e-8, maxit=3000)
+    print(f"[bench] cpu_baseline: assembly {t1 - t0:.1f}s", file=sys.stderr, flush=True)
+    y, its, reason, rn = cport.solve(mesh.num_nodes, rp, ci, vals, F, method="tfqmr", pc="ilu0", rtol=1e-8, maxit=maxit)
     t2 = time.time()
-    _, Fn = cport.assemble("ns", m.points, m.tets, U - y, Re, mask, g, rp, ci)      # line-search residual
+    print(f"[bench] cpu_baseline: tfqmr {its} its reason {reason} in {t2 - t1:.1f}s", file=sys.stderr, flush=True)
+    _, Fn = cport.assemble("ns", mesh.points, mesh.tets, U - y, Re, mask, g, rp, ci)      # line-search residual
     t3 = time.time()
-    ndof = m.num_dofs
+    ndof = mesh.num_dofs
+    f0, f1 = float(np.linalg.norm(F)), float(np.linalg.norm(Fn))
+    bound = "" if reason > 0 else f" -- NOT converged within {maxit} iterations (||r||/||b|| {rn / f0:.1e}): upper bound"
     return {"value": round(ndof / (t3 - t0) / 1e6, 4), "unit": "M-DOF/s", "cores": nthr, "kind": "port",
-            "sample": f"1 Newton iteration on duct {sample_cells} = {m.num_tets} tets / {ndof} dofs at Re={Re:.1f} "
-                      f"(same Re*h as the full run): C/OpenMP assembly {t1 - t0:.2f}s + tfqmr/bjacobi({nthr})-ILU(0) "
+            "t_asm_s": round(t1 - t0, 2), "t_solve_s": round(t2 - t1, 2), "t_residual_s": round(t3 - t2, 2),
+            "ksp_its": its, "ksp_reason": reason,
+            "sample": f"the GPU line's own workload: 1 Newton iteration at the Stokes solution on {mesh.num_tets} tets / "
+                      f"{ndof} dofs, Re={Re:g}: C/OpenMP assembly {t1 - t0:.2f}s + tfqmr/bjacobi({nthr})-ILU(0) "
                       f"{t2 - t1:.2f}s ({its} its, reason {reason}) + residual {t3 - t2:.2f}s; "
-                      f"||F|| {np.linalg.norm(F):.2e} -> {np.linalg.norm(Fn):.2e}"}
+                      f"||F|| {f0:.2e} -> {f1:.2e}{bound}"}
 
 
 def pmc_traffic(kernel_substr="k_spmv<2, 1"):
@@ -93,73 +97,46 @@ def pmc_traffic(kernel_substr="k_spmv<2, 1"):
         return None
     return fetch + write
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=str, default="300,75,75")
-    ap.add_argument("--length", type=float, default=4.0, help="duct length of the single-GPU share")
-    ap.add_argument("--re", type=float, default=200.0)
-    ap.add_argument("--ksp", type=str, default="bicgstab")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f64-rerun", action="store_true", help="skip the all-fp64 repetition of the timed steps")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
-    ap.add_argument("--strong", action="store_true",
-                    help="N>1: partition the SAME --cells mesh over the ranks instead of refining the duct with N")
-    args = ap.parse_args()
+def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on):
+    """(P, n_dof_global, n_tets_global, description, host_inputs) of one BASELINE config on this rank.
+    Config 5 (duct): x-slab element partition, every rank meshes only its own slab (partition.duct_slab_part).
+    Configs 3 / 4: the global mesh is built on every rank and RCB-partitioned (setup cost, not timed)."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
+    dev = f"cuda:{local_rank}"
+    host = None
+    if cfg == 5:
+        if dist_on:
+            part = PT.duct_slab_part(cells, length, rank, world)
+            P = FlowProblem.from_part(part, device=dev, **opts)
+        else:
+            mesh = M.duct_mesh(cells, length)
+            bcs = B.duct_bcs(mesh)
+            P = FlowProblem(mesh, bcs, device=dev, **opts)
+            host = (mesh, bcs)
+        nd = 4 * (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+        nt = 6 * cells[0] * cells[1] * cells[2]
+        desc = f"duct [0,{length:g}]x[-.5,.5]^2, {cells[0]}x{cells[1]}x{cells[2]} cells"
+    else:
+        if cfg == 3:                       # LidDrivenNavierStokesFlow.py extended to the unit cube (SURVEY 8, config 3)
+            mesh = M.cavity_mesh(cells[0])
+            bcs = B.cavity_bcs(mesh)
+            desc = f"lid-driven unit cube, {cells[0]}^3 cells"
+        else:                              # NavierStokesChannelFlow.py two-stream inlet, ratio 0.5 (config 4)
+            mesh = M.channel_mesh(cells)
+            bcs = B.channel_bcs(mesh, *B.two_stream_profiles(0.5))
+            desc = f"two-stream channel 4x1x1, {cells[0]}x{cells[1]}x{cells[2]} cells, flowrate ratio 0.5"
+        P = FlowProblem.distributed(mesh, bcs, device=dev, **opts) if dist_on else FlowProblem(mesh, bcs, device=dev, **opts)
+        host = (mesh, bcs)
+        nd, nt = mesh.num_dofs, mesh.num_tets
+    return P, nd, nt, desc, host
 
+
+def timed_newton_steps(P, U, steps, warmup, world):
+    """W untimed + K timed Newton iterations of a real sequence from the Stokes solution U (restarted when it has
+    converged); barrier + synchronize on both sides, MAX over ranks.  Returns (ms_per_step, log)."""
     import torch
     import torch.distributed as dist
-    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
-    from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    force_dist = bool(os.environ.get("SNS_FORCE_DIST"))          # rehearse the partitioned path with one rank
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29561")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-
-    cells = tuple(int(c) for c in args.cells.split(","))
-    opts = dict(reynolds=args.re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
-    for kv in args.opt:
-        k, v = kv.split("=", 1)
-        opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
-    weak = (world > 1 or force_dist) and not args.strong      # SNS_FORCE_DIST=1: rehearse the N>1 code path with one rank
-    if weak:
-        # weak scaling: the duct is refined uniformly so that every GPU keeps about the single-GPU share
-        # (--cells tets): cells x N^(1/3) per direction, same geometry and Re.  Ranks own x-slabs; each rank
-        # meshes only its own slab (+ one ghost cell layer), never the global mesh.
-        from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
-        sc = float(world) ** (1.0 / 3.0)
-        cells = tuple(int(round(c * sc)) for c in cells)
-        length = args.length
-        part = PT.duct_slab_part(cells, length, rank, world)
-        P = FlowProblem.from_part(part, device=f"cuda:{local_rank}", **opts)
-        n_dof_global = 4 * (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
-        n_tets_global = 6 * cells[0] * cells[1] * cells[2]
-    else:
-        length = args.length
-        mesh = M.duct_mesh(cells, length)
-        bcs = B.duct_bcs(mesh)
-        if world > 1 or force_dist:
-            P = FlowProblem.distributed(mesh, bcs, device=f"cuda:{local_rank}", **opts)
-        else:
-            P = FlowProblem(mesh, bcs, device=f"cuda:{local_rank}", **opts)
-        n_dof_global = mesh.num_dofs
-        n_tets_global = mesh.num_tets
-    U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
-    if sres.reason <= 0:
-        raise RuntimeError(f"Stokes solve did not converge: {sres}")
 
     def barrier():
         torch.cuda.synchronize()
@@ -167,28 +144,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    w = U.clone()
-    seq = 0
+    state = {"w": U.clone(), "seq": 0}
     log = []
 
     def step():
-        nonlocal w, seq
-        w, r = P.newton_solve(w)
-        seq += 1
+        w, r = P.newton_solve(state["w"])
+        state["w"] = w
+        state["seq"] += 1
         log.append((r.fnorms[-1] if r.fnorms else float("nan"), r.ksp_its, r.reason))
-        if r.reason == 2 or r.reason == 3 or seq >= 30:       # sequence converged: start over
-            w = U.clone()
-            seq = 0
-        return r
+        if r.reason == 2 or r.reason == 3 or state["seq"] >= 30:       # sequence converged: start over
+            state["w"] = U.clone()
+            state["seq"] = 0
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     P.reset_timings()
     P.time_kernels(True)
     log.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
@@ -197,60 +172,108 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    ms_per_step = dt / max(1, args.steps) * 1e3
+    return dt / max(1, steps) * 1e3, log, state["w"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=5, choices=[3, 4, 5],
+                    help="BASELINE config: 5 = 10.1 M-tet duct Re 200 (headline), 3 = 55^3 cavity Re 100, "
+                         "4 = 240x60x60 two-stream channel Re 50")
+    ap.add_argument("--cells", type=str, default=None)
+    ap.add_argument("--length", type=float, default=4.0, help="duct length")
+    ap.add_argument("--re", type=float, default=None)
+    ap.add_argument("--ksp", type=str, default="bicgstab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-maxit", type=int, default=200, help="iteration bound of the CPU baseline's Krylov solve")
+    ap.add_argument("--no-f64-rerun", action="store_true", help="skip the all-fp64 repetition of the timed steps")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaling layout after the headline")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
+    ap.add_argument("--strong", action="store_true", help="(default since round 2; kept for old command lines)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    force_dist = bool(os.environ.get("SNS_FORCE_DIST"))          # rehearse the partitioned path with one rank
+    dist_on = world > 1 or force_dist
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    cfg = args.config
+    default_cells = {5: "300,75,75", 4: "240,60,60", 3: "55,55,55"}[cfg]
+    cells = tuple(int(c) for c in (args.cells or default_cells).split(","))
+    Re = args.re if args.re is not None else {5: 200.0, 4: 50.0, 3: 100.0}[cfg]
+    opts = dict(reynolds=Re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
+    length = args.length
+
+    # ---- headline: the SAME mesh on N GPUs (strong scaling; N = 1 is the mesh on one GPU) ----------------------
+    P, n_dof_global, n_tets_global, desc, host = build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on)
+    U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
+    if sres.reason <= 0:
+        raise RuntimeError(f"Stokes solve did not converge: {sres}")
+    ms_per_step, log, w = timed_newton_steps(P, U, args.steps, args.warmup, world)
     value = n_dof_global / (ms_per_step * 1e-3) / 1e6
 
     tm = P.timings()
     kt = P.kernel_times()
     s = P.sizes()
+    ctr = P.counters()
     # K1 (Jacobian + residual assembly) timed on its own after the timed region: HIP events around 5 passes
     asm_ms = P.bench_assemble(w, "ns", 5)
     asm_bytes = 2480.0 * s["n_tets"]                   # 2480 B/tet
     # the same K steps once more with EVERY array in fp64 (no fp32 copies inside the preconditioner), reported
     # beside the headline so that the effect of the mixed-precision preconditioner is on record
     all_f64 = None
-    if P.options.amg_f32_matrix and not args.no_f64_rerun:
-        main_log = list(log)
+    fmt0 = int(P.options.amg_f32_matrix)
+    if fmt0 and not args.no_f64_rerun:
         P.set_options(amg_f32_matrix=0)
-        w, seq = U.clone(), 0
-        for _ in range(args.warmup):
-            step()
-        log.clear()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt64 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt64], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt64 = float(t)
-        ms64 = dt64 / max(1, args.steps) * 1e3
+        ms64, log64, _ = timed_newton_steps(P, U, args.steps, args.warmup, world)
         all_f64 = {"value": round(n_dof_global / (ms64 * 1e-3) / 1e6, 3), "unit": "M-DOF/s", "ms_per_step": round(ms64, 3),
-                   "ksp_its": [b for _, b, _ in log]}
-        P.set_options(amg_f32_matrix=1)
-        log[:] = main_log
+                   "ksp_its": [b for _, b, _ in log64]}
+        P.set_options(amg_f32_matrix=fmt0)
     # dominant kernel: the level-0 block-Jacobi sweep of the AMG cycle (3 of the 5 fine-level matrix passes
     # per preconditioner application).  Algorithmic bytes per launch:
     #   per nonzero block: values (64 B as the preconditioner's fp32 copy, 128 B in fp64) + 4 B column index
     #   per block row: 4 rowptr + 32 x + 32 b + 128 Dinv + 32 y = 228 B
-    f32 = bool(P.options.amg_f32_matrix)
-    kname = "k_spmv_f32<SPMV_JACOBI,FINE>" if f32 else "k_spmv<SPMV_JACOBI,FINE>"
+    #   fp16 copy: 32 B values + 4 B index per block, + 16 B of row scales per block row
+    fmt = int(P.options.amg_f32_matrix)
+    kname = {0: "k_spmv<SPMV_JACOBI,FINE>", 1: "k_spmv_lp<SPMV_JACOBI,FINE,fp32>", 2: "k_spmv_lp<SPMV_JACOBI,FINE,fp16>"}[fmt]
     jac_ms, jac_calls = kt["jacobi"]
-    alg_bytes = (68.0 if f32 else 132.0) * s["nnzb"] + 228.0 * s["n_owned"]
+    alg_bytes = {0: 132.0, 1: 68.0, 2: 36.0}[fmt] * s["nnzb"] + (228.0 + (16.0 if fmt == 2 else 0.0)) * s["n_owned"]
     roofline = None
     if jac_calls > 0:
         avg_ms = jac_ms / jac_calls
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("k_spmv_f32<2, 1" if f32 else "k_spmv<2, 1"),
+                    "traffic": pmc_traffic({0: "k_spmv<2, 1", 1: "k_spmv_lp<2, 1, 0, 1>", 2: "k_spmv_lp<2, 1, 0, 2>"}[fmt])
+                               if cfg == 5 else None,
                     "kernel": kname, "avg_launch_ms": round(avg_ms, 5),
                     "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
                     "assembly_kernels": {"avg_ms": round(asm_ms, 4), "algorithmic_bytes": asm_bytes,
                                          "achieved": round(asm_bytes / (asm_ms * 1e-3) / 1e9, 1),
                                          "frac": round(asm_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "nominal: SURVEY 8d's 2480 B/tet over the kernel time; the scratch-free "
+                                                 "kernels never move the 2 KiB/tet element matrix (PMC traffic 0.25-0.37x "
+                                                 "of that) -- their honest bound is the fp64-VALU figure below",
                                          "path": "scratch-free (k_fused_offdiag + k_fused_diag)"
                                                  if P.options.assembly_fused else "staged (k_element + gathers)",
                                          # secondary: executed fp64 VALU flops of the scratch-free path,
@@ -266,36 +289,59 @@ def main():
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "precision_note": "operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "
-                          "smoother/residual passes read an fp32 copy of the level matrices (arithmetic f64)"
-                          if P.options.amg_f32_matrix else "all f64",
-        "config": {"workload": f"duct [0,{length:g}]x[-.5,.5]^2, {cells[0]}x{cells[1]}x{cells[2]} cells = {n_tets_global} tets, "
-                               f"{n_dof_global} dofs, Re={args.re:g}, Newton iteration (assemble J+F, AMG setup, "
+        "precision_note": ("operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "
+                           "smoother/residual passes read a " + {1: "fp32", 2: "row-scaled fp16"}[fmt] + " copy of the level "
+                           "matrices (vectors and arithmetic f64; same Krylov iteration counts); the strict all-f64 "
+                           "figure of the same steps is under all_f64_preconditioner") if fmt else "all f64",
+        "config": {"workload": f"BASELINE config {cfg}: {desc} = {n_tets_global} tets, "
+                               f"{n_dof_global} dofs, Re={Re:g}, Newton iteration (assemble J+F, AMG setup, "
                                f"{args.ksp} rtol 1e-8, bt line search)",
-                   "parallelism": (f"x-slab element partition x{world}, {n_tets_global // world} tets per GPU"
-                                   if world > 1 else "single GPU"),
-                   "scaling_note": ("weak: every GPU keeps BASELINE config 5's 10.1 M-tet share (duct refined by "
-                                    "N^(1/3)); --strong splits the one 10.1 M-tet mesh N ways (DESIGN.md section 7)"
-                                    if weak else ("strong: the one mesh split N ways" if world > 1 else
-                                                  "N=1 is BASELINE config 5's mesh on one GPU")),
+                   "parallelism": (f"element partition x{world} ({'x-slabs' if cfg == 5 else 'RCB'}), "
+                                   f"{n_tets_global // world} tets per GPU" if world > 1 else "single GPU"),
+                   "scaling_note": "strong: the one mesh split N ways (north_star: >= 6x at 8 GPUs on the 10 M-tet duct); "
+                                   "the weak layout is under weak_scaling",
                    "newton_log_fnorm_kspits_reason": [(float(f"{a:.3e}"), b, c) for a, b, c in log],
                    "phase_ms_per_step": {"assemble": round(tm.assemble_ms / args.steps, 3),
                                          "pc_setup": round(tm.pc_setup_ms / args.steps, 3),
                                          "krylov": round(tm.krylov_ms / args.steps, 3)},
+                   "krylov_loop_last_solve": {"host_syncs": ctr["host_syncs"], "allreduces": ctr["allreduces"],
+                                              "halo_exchanges": ctr["exchanges"], "its": log[-1][1] if log else None},
                    "amg_levels": tm.amg_levels, "stokes_its": sres.its},
         "roofline": roofline,
         "all_f64_preconditioner": all_f64,
+        "weak_scaling": None,
+        "cpu_baseline": None,
     }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(re_full=args.re, full_ny=cells[1])
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+    U_host = U.cpu().numpy() if (rank == 0 and world == 1 and not dist_on and host is not None) else None
     P.close()
-    if world > 1 or force_dist:
+    del P, U, w
+    torch.cuda.empty_cache()
+
+    # ---- second key for N > 1: the weak layout (every GPU keeps the single-GPU share) --------------------------
+    if cfg == 5 and dist_on and not args.no_weak:
+        sc = float(world) ** (1.0 / 3.0)
+        wcells = tuple(int(round(c * sc)) for c in cells)
+        Pw, nd_w, nt_w, desc_w, _ = build_problem(5, wcells, length, Re, world, rank, local_rank, opts, True)
+        Uw, sw = Pw.stokes_solve()
+        if sw.reason > 0:
+            ms_w, log_w, _ = timed_newton_steps(Pw, Uw, args.steps, args.warmup, world)
+            out["weak_scaling"] = {"value": round(nd_w / (ms_w * 1e-3) / 1e6, 3), "unit": "M-DOF/s",
+                                   "ms_per_step": round(ms_w, 3), "scaling": "weak",
+                                   "workload": f"{desc_w} = {nt_w} tets, {nd_w} dofs ({nt_w // world} tets per GPU)",
+                                   "ksp_its": [b for _, b, _ in log_w], "stokes_its": sw.its}
+        else:
+            out["weak_scaling"] = {"error": f"Stokes solve reason {sw.reason}"}
+        Pw.close()
+
+    if rank == 0:
+        if U_host is not None and not args.no_cpu_baseline:
+            mesh, bcs = host
+            mask, g = bcs.flatten()
+            out["cpu_baseline"] = cpu_baseline(mesh, mask, g, U_host, Re, maxit=args.cpu_maxit)
+        print(json.dumps(out), flush=True)
+    if dist_on:
         dist.destroy_process_group()
 
 

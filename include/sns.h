@@ -93,8 +93,10 @@ typedef struct {
     double amg_omega;       /* block-Jacobi damping (0.8)                            */
     int    monitor;         /* 1: print ||r|| per Krylov/Newton iteration (ksp_monitor / snes_monitor :201,:276) */
     int    corrected_convection; /* 0 = reference as written (dot(u,grad(.)) :241,:247); 1 = (u.grad)(.) */
-    int    amg_f32_matrix;  /* 1: the AMG smoother/residual passes read an fp32 copy of each level
-                               operator (vectors and arithmetic stay fp64; the Krylov operator stays fp64) */
+    int    amg_f32_matrix;  /* storage of the matrix copy the AMG smoother/residual passes read (vectors, D^-1, ALL
+                               arithmetic and the Krylov operator stay fp64): 0 = the fp64 operator itself,
+                               1 = fp32 copy, 2 (default) = fp16 copy with one fp32 scale per dof row (row-max
+                               normalisation; relative perturbation of the preconditioner's matrix <= 2^-11) */
     int    amg_nu_coarse;   /* smoothing sweeps on level 1 (and deeper unless overridden) (4; 0 = same as amg_nu):
                                coarse sweeps are cheap and plain aggregation needs them */
     int    amg_nu_deep;     /* sweeps on levels >= 3 (2; 0 = same as amg_nu_coarse): these levels are launch-bound */
@@ -115,6 +117,8 @@ typedef struct {
                                nu = 1/Re: LidDrivenNavierStokesFlow.py:96-104) */
     double stokes_beta;     /* 2-D handles only: mu_T = stokes_beta * h^2 (0.2: DFG_2D_Validation.py:104-106;
                                a0/(4 nu), a0 = 1/3: LidDrivenNavierStokesFlow.py:98-100) */
+    int    amg_fine_cycle;  /* shape of the AMG cycle on the fine level (single GPU): 0 = V(1,1) (default),
+                               1 = V(0,1) (no pre-smoothing), 2 = V(1,0) (no post-smoothing) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

@@ -126,7 +126,8 @@ struct sns_ctx {
     int32_t n_bnd = 0;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_x = nullptr, ev_side = nullptr;
-    bool no_overlap = false;                          // extra partial-sum blocks of the boundary pass of a split SpMV+dot
+    bool no_overlap = false;
+    bool no_windows = false;                         // SNS_NO_WINDOWS: A/B switch for the windowed LDS gathers                          // extra partial-sum blocks of the boundary pass of a split SpMV+dot
     std::unique_ptr<Comm> comm;
     // distributed coarsest level: global dense inverse, replicated on every rank
     int cg_maxn = 0;                              // padded owned coarsest nodes per rank
@@ -278,34 +279,47 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
     }
 }
 
-// Preconditioner passes (Jacobi sweep, residual) of the AMG cycle: fp32 matrix copy when enabled.
+// Preconditioner passes (Jacobi sweep, residual) of the AMG cycle on the low-precision copy of the level matrix
+// (amg_f32_matrix: 1 = fp32, 2 = fp16 with row scales), windowed LDS gathers where the level has windows.
+template <int MODE, int FINE, int SPLIT, int FMT>
+void launch_lp(sns_ctx* h, const Level& L, int32_t rows, hipStream_t st, const double* x, double* y, const double* b,
+               double omega) {
+    const int grid = (rows + 63) / 64;
+    if (grid == 0) return;
+    const void* vals = FMT == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
+    hipLaunchKernelGGL((k_spmv_lp<MODE, FINE, SPLIT, FMT>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
+                       L.scale16, x, y, b, L.dinv, omega, SPLIT == 2 ? h->bnd_rows : (const int32_t*)nullptr,
+                       SPLIT == 1 ? h->bnd_flag : (const uint8_t*)nullptr);
+}
+template <int MODE, int FMT>
+void launch_lp_fmt(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b, double omega,
+                   Split sp) {
+    hipStream_t st = sp.stream ? sp.stream : h->stream;
+    const bool fine = (&L == &h->levels[0]);
+    if (fine && sp.mode == 1) {
+        launch_lp<MODE, 1, 1, FMT>(h, L, rows, st, x, y, b, omega);
+    } else if (fine && sp.mode == 2) {
+        launch_lp<MODE, 1, 2, FMT>(h, L, h->n_bnd, st, x, y, b, omega);
+    } else if (fine) {
+        time_begin(h, MODE);
+        launch_lp<MODE, 1, 0, FMT>(h, L, rows, st, x, y, b, omega);
+        time_end(h);
+    } else {
+        launch_lp<MODE, 0, 0, FMT>(h, L, rows, st, x, y, b, omega);
+    }
+}
+inline int lp_format(const sns_ctx* h, const Level& L) {
+    if (h->opt.amg_f32_matrix == 2 && L.vals16) return 2;
+    if (h->opt.amg_f32_matrix && L.vals32) return 1;
+    return 0;
+}
 template <int MODE>
 void launch_pc_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b,
                     double omega, Split sp = Split()) {
-    if (!(h->opt.amg_f32_matrix && L.vals32)) {
-        launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr, sp);
-        return;
-    }
-    hipStream_t st = sp.stream ? sp.stream : h->stream;
-    const bool fine = (&L == &h->levels[0]);
-    if (sp.mode == 2) rows = h->n_bnd;
-    const int grid = (rows + 63) / 64;
-    if (grid == 0) return;
-    if (fine && sp.mode == 1) {
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals32,
-                           x, y, b, L.dinv, omega, (const int32_t*)nullptr, h->bnd_flag);
-    } else if (fine && sp.mode == 2) {
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 2>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals32,
-                           x, y, b, L.dinv, omega, h->bnd_rows, (const uint8_t*)nullptr);
-    } else if (fine) {
-        time_begin(h, MODE);
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 1, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind,
-                           L.vals32, x, y, b, L.dinv, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
-        time_end(h);
-    } else {
-        hipLaunchKernelGGL((k_spmv_f32<MODE, 0, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind,
-                           L.vals32, x, y, b, L.dinv, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
-    }
+    const int fmt = lp_format(h, L);
+    if (fmt == 2) launch_lp_fmt<MODE, 2>(h, L, rows, x, y, b, omega, sp);
+    else if (fmt == 1) launch_lp_fmt<MODE, 1>(h, L, rows, x, y, b, omega, sp);
+    else launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr, sp);
 }
 
 // Level-0 pass whose input needs a halo exchange first (multi-GPU): the exchange of xe's ghost tail runs on the
@@ -332,7 +346,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         pass(Split());
         return SNS_OK;
     }
-    const int gs = pc && h->opt.amg_f32_matrix && L.vals32 ? (rows + 63) / 64 : (rows + 31) / 32;
+    const int gs = (rows + 31) / 32;                 // partial sums exist in the fp64 AX_DOT pass only
     Split s1, s2;
     s1.mode = 1;
     s2.mode = 2;
@@ -1021,10 +1035,23 @@ int pc_setup(sns_ctx* h) {
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
         if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
-            if (!L.vals32) SNS_TRY(dev_alloc(&L.vals32, (size_t)L.nnzb * 16));
-            if (L.nnzb > 0)
-                hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.nnzb * 16)), dim3(256), 0, h->stream, L.nnzb * 16, L.vals,
-                               L.vals32);
+            if (h->opt.amg_f32_matrix == 2) {
+                if (!L.vals16) {
+                    uint2* v16 = nullptr;
+                    SNS_TRY(dev_alloc(&v16, (size_t)L.nnzb * 4));
+                    L.vals16 = v16;
+                    SNS_TRY(dev_alloc(&L.scale16, (size_t)4 * std::max(1, L.n)));
+                }
+                if (rows > 0)
+                    hipLaunchKernelGGL(k_cvt_h16, dim3((unsigned)((4 * (int64_t)rows + 255) / 256)), dim3(256), 0, h->stream,
+                                       rows, L.rowptr, L.vals, (uint2*)L.vals16, L.scale16);
+            }
+            if (h->opt.amg_f32_matrix != 2 || std::getenv("SNS_BOTH_LP")) {
+                if (!L.vals32) SNS_TRY(dev_alloc(&L.vals32, (size_t)L.nnzb * 16));
+                if (L.nnzb > 0)
+                    hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.nnzb * 16)), dim3(256), 0, h->stream, L.nnzb * 16, L.vals,
+                                       L.vals32);
+            }
         }
         if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
@@ -1191,6 +1218,28 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         for (int s = 0; s < 8; ++s) {       // even count: result ends in x
             launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
             std::swap(cur, oth);
+        }
+        return SNS_OK;
+    }
+    if (l == 0 && !L.xg && h->opt.amg_fine_cycle != 0 && rows > 0) {
+        // experimental fine-level cycle shapes (single GPU): 1 = V(0,1): no pre-smoothing, the right-hand side itself
+        // is restricted; 2 = V(1,0): no post-smoothing.  One fine-level matrix pass per cycle instead of two.
+        Level& C = h->levels[1];
+        if (h->opt.amg_fine_cycle == 1) {
+            hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, b, C.b);
+            SNS_TRY(coarse_cycle(h, 1, C.b, C.x));
+            double* tmp = h->pong[0];
+            HIP_TRY(hipMemsetAsync(tmp, 0, 4 * (size_t)rows * sizeof(double), h->stream));
+            hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, tmp);
+            launch_pc_spmv<SPMV_JACOBI>(h, L, rows, tmp, x, b, om);
+        } else {
+            hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, x);
+            launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, x, L.r, b, 0.0);
+            hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
+            SNS_TRY(coarse_cycle(h, 1, C.b, C.x));
+            hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, x);
         }
         return SNS_OK;
     }
@@ -1697,7 +1746,7 @@ void sns_default_options(sns_options* o) {
     o->amg_omega = 0.8;
     o->monitor = 0;
     o->corrected_convection = 0;
-    o->amg_f32_matrix = 1;
+    o->amg_f32_matrix = 2;
     o->amg_nu_coarse = 4;
     o->amg_nu_deep = 2;
     o->amg_nu_l2 = 6;
@@ -1707,6 +1756,7 @@ void sns_default_options(sns_options* o) {
     o->amg_post_exchange = 1;
     o->stokes_viscosity = 1.0;
     o->stokes_beta = 0.2;
+    o->amg_fine_cycle = 0;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -1882,7 +1932,7 @@ int sns_destroy(sns_handle h) {
     fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->gext); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
-        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32);
+        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);
@@ -2286,8 +2336,10 @@ int sns_bench_spmv(sns_handle h, const double* x, double* y, int reps, double* m
     return SNS_OK;
 }
 // interleaved A/B micro-benchmark of kernel variants on the assembled level-0 operator (methodology:
-// variants timed alternately in ONE process).  which 0: fp64 y=Ax, 1: fp32-matrix Jacobi sweep;
-// variant 0/1 = default / non-temporal matrix loads.  ms_out[2] = average ms of variant 0 and 1.
+// variants timed alternately in ONE process).  ms_out[v] = average launch ms of variant v.
+//   which 0: fp64 y = Ax, default loads (0) vs non-temporal matrix stream (1, production)
+//   which 3: fp64 y = Ax, production (0) vs the r1e loop (1)
+//   which 1: low-precision Jacobi sweep, fp16 row-scaled (0) vs fp32 (1) (needs both copies: SNS_BOTH_LP=1)
 int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]) {
     if (!h || !ms_out || rounds <= 0 || reps <= 0) return SNS_E_ARG;
     if (!h->has_matrix) { set_error("bench_variants before a matrix was assembled"); return SNS_E_STATE; }
@@ -2296,31 +2348,23 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
     double *x, *y, *b;
     SNS_TRY(get_vec(h, 10, &x)); SNS_TRY(get_vec(h, 11, &y)); SNS_TRY(get_vec(h, 12, &b));
     hipLaunchKernelGGL(k_fill_pattern, dim3(vec_grid(4 * (int64_t)rows)), dim3(256), 0, h->stream, 4 * (int64_t)rows, x);
-    if ((which == 1 || which == 2 || which >= 10) && !L.vals32) { set_error("fp32 matrix copy not built (pc_setup with amg_f32_matrix)"); return SNS_E_STATE; }
+    if (which == 1 && (!L.vals16 || !L.vals32)) { set_error("which 1 needs both the fp16 and the fp32 copy (SNS_BOTH_LP=1)"); return SNS_E_STATE; }
+    const int saved_fmt = h->opt.amg_f32_matrix;
     double tot[2] = {0, 0};
     for (int r = 0; r < rounds; ++r)
         for (int v = 0; v < 2; ++v) {
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
             for (int i = 0; i < reps; ++i) {
-                if (which >= 10) {                // f32 Jacobi: production vs production with (which-10) KiB of unused
-                                                  // dynamic LDS per workgroup, i.e. fewer resident waves per CU
-                    const int grid = (rows + 63) / 64;
-                    hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0, 0>), dim3(grid), dim3(256), v ? (size_t)(which - 10) * 1024 : 0,
-                                       h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
-                } else if (which == 3) {          // fp64 y = Ax: production (nt, cooperative loads) vs the r1e loop
-                    const int grid = (rows + 31) / 32;
+                const int grid = (rows + 31) / 32;
+                if (which == 3) {
                     if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                     else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                 } else if (which == 0) {
-                    const int grid = (rows + 31) / 32;
                     if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                     else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                 } else {
-                    const int grid = (rows + 63) / 64;
-                    // which = 1: production vs variant 1; which = 2: production vs variant 2
-                    if (v && which == 1) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
-                    else if (v) hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
-                    else hipLaunchKernelGGL((k_spmv_f32<SPMV_JACOBI, 1, 0, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals32, x, y, b, L.dinv, 0.7, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+                    h->opt.amg_f32_matrix = v ? 1 : 2;
+                    launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x, y, b, 0.7);
                 }
             }
             HIP_TRY(hipEventRecord(h->ev1, h->stream));
@@ -2329,6 +2373,7 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
             HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
             tot[v] += ms / reps;
         }
+    h->opt.amg_f32_matrix = saved_fmt;
     ms_out[0] = tot[0] / rounds;
     ms_out[1] = tot[1] / rounds;
     HIP_TRY(hipGetLastError());

@@ -52,6 +52,8 @@ struct Level {
     double* vals = nullptr;              // nnzb*16, block row-major
     double* dinv = nullptr;              // n*16
     float* vals32 = nullptr;             // fp32 copy of vals for the preconditioner passes (amg_f32_matrix)
+    void* vals16 = nullptr;              // fp16 copy, row-scaled (amg_f32_matrix = 2): 4 halfs per block row
+    float* scale16 = nullptr;            // its scales, one per dof row
     // to the next coarser level
     int32_t nc = 0;
     int32_t* agg = nullptr;              // n

@@ -53,11 +53,12 @@ __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* col
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial, const int32_t* row_list, const uint8_t* skip,
                        int partial_off);
-template <int MODE, int FINE, int VAR, int SPLIT>
-__global__ void k_spmv_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const float* vals,
-                           const double* x, double* y, const double* bvec, const double* dinv, double omega,
-                           const int32_t* row_list, const uint8_t* skip);
+template <int MODE, int FINE, int SPLIT, int FMT>
+__global__ void k_spmv_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
+                          const float* scale, const double* x, double* y, const double* bvec, const double* dinv,
+                          double omega, const int32_t* row_list, const uint8_t* skip);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
+__global__ void k_cvt_h16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
 __global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);

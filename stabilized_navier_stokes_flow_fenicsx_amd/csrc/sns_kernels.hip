@@ -1451,15 +1451,43 @@ __device__ __forceinline__ double quad_bcast(double v) { return quad_perm<J * 0x
 template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true); }
 
-// VAR: 0 = production; 1, 2 = variants kept for the interleaved A/B harness (sns_bench_variants)
-template <int MODE, int FINE, int VAR, int SPLIT>
-__global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ colind,
-                                                  const float* __restrict__ vals, const double* __restrict__ x,
-                                                  double* __restrict__ y, const double* __restrict__ bvec,
-                                                  const double* __restrict__ dinv, double omega,
-                                                  const int32_t* __restrict__ row_list,
-                                                  const uint8_t* __restrict__ skip) {
+// k_spmv_lp: the preconditioner passes (Jacobi sweep, residual) on a LOW-PRECISION COPY of the level matrix.
+//   FMT 1: fp32 values (68 B per block with its index instead of 132 B)
+//   FMT 2: fp16 values with one fp32 scale per dof row (row-max normalisation: nothing overflows or underflows
+//          the half range), 36 B per block; (A x)_r = scale_r * sum_k half_rk x_k
+// Vectors, D^-1 and ALL arithmetic stay fp64, so the cycle remains a fixed linear operator in exact arithmetic of
+// a slightly perturbed matrix.  4 lanes per block row (16 block rows per wave).  The kernel is bound by VMEM issue /
+// L2 requests rather than bytes, so a step of 4 blocks issues as few, as wide loads as it can:
+//   * ONE index load per quad (lane j fetches the id of block k + j),
+//   * the x gather as TWO 16-B loads per lane: lane j fetches the WHOLE x block of column (k + j); DPP broadcasts
+//     hand the four blocks round (instead of four 8-B loads per lane),
+//   * the matrix row of lane r as 16-B loads: fp32: one per block; fp16: one per PAIR of blocks -- the fp16 copy
+//     stores the blocks of a row pair-interleaved ([row 0 of blocks k,k+1 | row 1 of k,k+1 | ...], 64 B per pair; an
+//     odd last block keeps the plain layout), so two blocks cost one load.
+// 7 (fp32) / 5 (fp16) VMEM instructions per lane and step instead of 9.
+//   SPLIT as in k_spmv (multi-GPU interior / boundary passes).
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ double lp_dot(const float4 a, const double2 xa, const double2 xb) {
+    return (double)a.x * xa.x + (double)a.y * xa.y + (double)a.z * xb.x + (double)a.w * xb.y;
+}
+__device__ __forceinline__ double lp_dot(const f16x4_t a, const double2 xa, const double2 xb) {
+    return (double)(float)a.x * xa.x + (double)(float)a.y * xa.y + (double)(float)a.z * xb.x + (double)(float)a.w * xb.y;
+}
+template <int J>
+__device__ __forceinline__ double2 quad_bcast2(const double2 v) {
+    return make_double2(quad_bcast<J>(v.x), quad_bcast<J>(v.y));
+}
+
+template <int MODE, int FINE, int SPLIT, int FMT>
+__global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
+                                                 const float* __restrict__ scale, const double* __restrict__ x,
+                                                 double* __restrict__ y, const double* __restrict__ bvec,
+                                                 const double* __restrict__ dinv, double omega,
+                                                 const int32_t* __restrict__ row_list,
+                                                 const uint8_t* __restrict__ skip) {
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1472,11 +1500,10 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
     double acc0 = 0.0, acc1 = 0.0;
     // every lane of a quad walks the same row, so the loop trip count is quad-uniform (DPP needs all 4 lanes)
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
-    const float4* __restrict__ vp = reinterpret_cast<const float4*>(vals) + ((int64_t)s * 4 + r);
     // the row's b, x and D^-1 entries are requested BEFORE the block loop, so their latency hides behind it
-    // (-2..4 % against loading them in the epilogue)
-    double pre_b = 0.0, pre_x = 0.0;
+    double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
     double2 pre_d01 = make_double2(0.0, 0.0), pre_d23 = pre_d01;
+    if (FMT == 2 && live) sc = (double)scale[4 * (int64_t)row + r];
     if (MODE == SPMV_B_MINUS_AX && live) pre_b = bvec[4 * (int64_t)row + r];
     if (MODE == SPMV_JACOBI && live) {
         pre_b = bvec[4 * (int64_t)row + r];
@@ -1485,48 +1512,55 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
         pre_d01 = D2[0];
         pre_d23 = D2[1];
     }
-    // Per quad and step of 4 blocks: ONE index load (lane r fetches colind[k + r]; DPP hands the four ids
-    // round) instead of four broadcast loads, four 16-B matrix loads, four 8-B x loads (lane r fetches
-    // component r of each x block).  VAR = 2 keeps the four broadcast index loads for the A/B harness.
+    const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);       // FMT 1
+    const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);         // FMT 2: pairs
     int32_t k = s;
-    // VAR = 1 (A/B harness): the ids of the NEXT step are requested one step ahead (index -> x gather is a
-    // dependent chain of two memory round trips per step otherwise)
-    int32_t cnext = (VAR == 1 && k + 3 < e) ? colind[k + r] : 0;
     for (; k + 3 < e; k += 4) {
-        int32_t c0, c1, c2, c3;
-        if (VAR == 2) {
-            c0 = colind[k]; c1 = colind[k + 1]; c2 = colind[k + 2]; c3 = colind[k + 3];
+        const int32_t cme = colind[k + r];
+        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];                     // the whole x block of column (k + r)
+        if (FMT == 1) {
+            const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
+            acc0 += lp_dot(a0, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            acc1 += lp_dot(a1, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            acc0 += lp_dot(a2, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            acc1 += lp_dot(a3, quad_bcast2<3>(xa), quad_bcast2<3>(xb));
+            v32 += 16;
         } else {
-            int32_t cme;
-            if (VAR == 1) {
-                cme = cnext;
-                cnext = (k + 7 < e) ? colind[k + 4 + r] : 0;
-            } else {
-                cme = colind[k + r];
-            }
-            c0 = quad_bcast_i<0>(cme); c1 = quad_bcast_i<1>(cme); c2 = quad_bcast_i<2>(cme); c3 = quad_bcast_i<3>(cme);
+            const uint4 p0 = v16[0], p1 = v16[4];                 // row r of blocks (k, k+1) and (k+2, k+3)
+            const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0), h1 = *reinterpret_cast<const f16x8_t*>(&p1);
+            acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            acc0 += lp_dot(h1.lo, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            acc1 += lp_dot(h1.hi, quad_bcast2<3>(xa), quad_bcast2<3>(xb));
+            v16 += 8;
         }
-        const float4 a0 = vp[0], a1 = vp[4], a2 = vp[8], a3 = vp[12];
-        const double g0 = x[4 * (int64_t)c0 + r], g1 = x[4 * (int64_t)c1 + r];
-        const double g2 = x[4 * (int64_t)c2 + r], g3 = x[4 * (int64_t)c3 + r];
-        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                (double)a0.w * quad_bcast<3>(g0);
-        acc1 += (double)a1.x * quad_bcast<0>(g1) + (double)a1.y * quad_bcast<1>(g1) + (double)a1.z * quad_bcast<2>(g1) +
-                (double)a1.w * quad_bcast<3>(g1);
-        acc0 += (double)a2.x * quad_bcast<0>(g2) + (double)a2.y * quad_bcast<1>(g2) + (double)a2.z * quad_bcast<2>(g2) +
-                (double)a2.w * quad_bcast<3>(g2);
-        acc1 += (double)a3.x * quad_bcast<0>(g3) + (double)a3.y * quad_bcast<1>(g3) + (double)a3.z * quad_bcast<2>(g3) +
-                (double)a3.w * quad_bcast<3>(g3);
-        vp += 16;
     }
-    for (; k < e; ++k) {
-        const float4 a0 = vp[0];
-        const double g0 = x[4 * (int64_t)colind[k] + r];
-        acc0 += (double)a0.x * quad_bcast<0>(g0) + (double)a0.y * quad_bcast<1>(g0) + (double)a0.z * quad_bcast<2>(g0) +
-                (double)a0.w * quad_bcast<3>(g0);
-        vp += 4;
+    if (k < e) {                                                  // 1..3 blocks left; quad-uniform
+        const int32_t left = e - k;
+        const int32_t cme = colind[k + (r < left ? r : 0)];
+        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];
+        if (FMT == 1) {
+            acc0 += lp_dot(v32[0], quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            if (left > 1) acc1 += lp_dot(v32[4], quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            if (left > 2) acc0 += lp_dot(v32[8], quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+        } else {
+            if (left > 1) {
+                const uint4 p0 = v16[0];
+                const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0);
+                acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+                acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            }
+            if (left & 1) {                                       // the odd last block: plain layout, 8 B per row
+                const uint2 q = reinterpret_cast<const uint2*>(vals_v)[(int64_t)(e - 1) * 4 + r];
+                const f16x4_t hq = *reinterpret_cast<const f16x4_t*>(&q);
+                if (left == 1) acc0 += lp_dot(hq, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+                else acc0 += lp_dot(hq, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            }
+        }
     }
-    const double acc = acc0 + acc1;                 // (A x)[4*row + r]
+    const double acc = sc * (acc0 + acc1);          // (A x)[4*row + r]
     if (MODE == SPMV_B_MINUS_AX) {
         if (live) y[4 * (int64_t)row + r] = pre_b - acc;
     } else if (MODE == SPMV_JACOBI) {
@@ -1536,20 +1570,53 @@ __global__ __launch_bounds__(256) void k_spmv_f32(int32_t n_rows, const int32_t*
             y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
     }
 }
-#define SNS_INST_SPMV32(M, F, N, S)                                                                              \
-    template __global__ void k_spmv_f32<M, F, N, S>(int32_t, const int32_t*, const int32_t*, const float*,         \
-                                                    const double*, double*, const double*, const double*, double,  \
-                                                    const int32_t*, const uint8_t*);
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 1, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 2, 0)
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 0, 0, 0)
-SNS_INST_SPMV32(SPMV_JACOBI, 0, 0, 0)
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 1)
-SNS_INST_SPMV32(SPMV_B_MINUS_AX, 1, 0, 2)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 1)
-SNS_INST_SPMV32(SPMV_JACOBI, 1, 0, 2)
+#define SNS_INST_LP(M, F, S, T)                                                                                    \
+    template __global__ void k_spmv_lp<M, F, S, T>(int32_t, const int32_t*, const int32_t*, const void*,              \
+                                                   const float*, const double*, double*, const double*,              \
+                                                   const double*, double, const int32_t*, const uint8_t*);
+#define SNS_INST_LP_FMT(T)                \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, T) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 1, T) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 2, T) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 0, 0, T) \
+    SNS_INST_LP(SPMV_JACOBI, 1, 0, T)     \
+    SNS_INST_LP(SPMV_JACOBI, 1, 1, T)     \
+    SNS_INST_LP(SPMV_JACOBI, 1, 2, T)     \
+    SNS_INST_LP(SPMV_JACOBI, 0, 0, T)
+SNS_INST_LP_FMT(1)
+SNS_INST_LP_FMT(2)
+
+// fp16 copy of a BSR4 matrix with one scale per dof row, in the pair-interleaved layout k_spmv_lp<FMT 2> reads:
+// 4 lanes per block row, lane r owns dof row 4*row + r.  Block j of a row (j = k - rowptr[row]) that has a partner
+// (j ^ 1 within the row) lands in pair j >> 1, half j & 1; an odd last block keeps the plain position.
+__global__ __launch_bounds__(256) void k_cvt_h16(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                 const double* __restrict__ vals, uint2* __restrict__ out,
+                                                 float* __restrict__ scale) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = gid >> 2;
+    const int r = (int)(gid & 3);
+    if (row >= n_rows) return;
+    const int32_t s = rowptr[row], e = rowptr[row + 1];
+    double m = 0.0;
+    for (int32_t k = s; k < e; ++k) {
+        const double* a = vals + 16 * (int64_t)k + 4 * r;
+        m = fmax(m, fmax(fmax(fabs(a[0]), fabs(a[1])), fmax(fabs(a[2]), fabs(a[3]))));
+    }
+    const float sc = (float)m;
+    const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+    scale[4 * row + r] = sc;
+    const int32_t cnt = e - s;
+    for (int32_t k = s; k < e; ++k) {
+        const double* a = vals + 16 * (int64_t)k + 4 * r;
+        f16x4_t hv;
+        hv.x = (_Float16)(float)(a[0] * inv); hv.y = (_Float16)(float)(a[1] * inv);
+        hv.z = (_Float16)(float)(a[2] * inv); hv.w = (_Float16)(float)(a[3] * inv);
+        const int32_t j = k - s;
+        const bool paired = (j | 1) < cnt;
+        const int64_t dst = paired ? ((int64_t)s * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)k * 4 + r);
+        out[dst] = *reinterpret_cast<const uint2*>(&hv);
+    }
+}
 
 __global__ __launch_bounds__(256) void k_cvt_f32(int64_t n, const double* __restrict__ x, float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
