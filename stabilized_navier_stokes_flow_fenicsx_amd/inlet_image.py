@@ -1,5 +1,12 @@
 """Inlet image -> two-stream inlet data (host side; numpy / scipy / PIL only).
 
+``channel_from_image`` drives the structured 4x1x1 channel with the inlet profiles of ``inlet_contours``
+(the reference's own pipeline: contours -> FFT low-pass -> RDP -> P1 Poisson on a triangulation of each
+region); ``method="pixel"`` selects the older pixel-grid restatement below, which the tests keep as an
+independent sanity bound for the contour pipeline.
+
+Pixel-grid variant:
+
 The reference turns a black-on-white PNG of the nozzle wall (e.g.
 ``InletImages/PlusF_final.png``: a black band on white) into
   * two 2-D regions -- inside the band (stream 1) and outside it (stream 2) --
@@ -136,13 +143,20 @@ def solve_inlet_profiles(img_fname: str, flowrate_ratio: float) -> InletData:
     return InletData(gray, region, out[0][0], out[1][0], out[0][1], out[1][1])
 
 
-def channel_from_image(img_fname: str, flowrate_ratio: float, cells, *, nozzle_length: float = 0.5):
-    """(mesh, DirichletSet, InletData) of the 4x1x1 channel driven by an inlet image.
+def channel_from_image(img_fname: str, flowrate_ratio: float, cells, *, nozzle_length: float = 0.5,
+                       method: str = "contours"):
+    """(mesh, DirichletSet, inlet data) of the 4x1x1 channel driven by an inlet image.
 
     Facet tags as image2gmsh3D.py:435-438 (inlet_1=1, inlet_2=2, outlet=3, wall=4): inlet facets are
     classified by the image region under their centroid, facets under the dark band are wall.  The
     nozzle walls (band extruded over x in [0, nozzle_length]) become no-slip nodes."""
-    data = solve_inlet_profiles(img_fname, flowrate_ratio)
+    if method == "contours":
+        from .inlet_contours import solve_inlet_profiles as solve_contours
+        data = solve_contours(img_fname, flowrate_ratio, max_pixels=1024)
+    elif method == "pixel":
+        data = solve_inlet_profiles(img_fname, flowrate_ratio)
+    else:
+        raise ValueError("method must be 'contours' or 'pixel'")
     m = M.channel_mesh(cells)
     t = m.meta["tags"]
     inl = np.nonzero((m.facet_tags == t["inlet_1"]) | (m.facet_tags == t["inlet_2"]))[0]

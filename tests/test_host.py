@@ -425,3 +425,79 @@ def test_xdmf_output_is_the_hdf5_container_the_reference_reads(tmp_path):
     assert len(g["G"].keys()) == 37 and g["G"]["d36"][-1] == 36 and g["empty"].shape == (0, 3)
     back = read_datasets(str(tmp_path / "many.h5"))
     assert len(back) == 38 and back["/G/d05"].tolist() == list(range(6))
+
+
+@pytest.mark.parametrize("name", ["PlusF_final", "asym_offset", "Triangle"])
+def test_inlet_contour_pipeline_on_reference_images(name):
+    """image2inlet.py:58-139,240-353 on the reference's own inlet images (tests/golden/inlet_*.png: box-filtered
+    copies of NavierStokes/InletImages/*.png, oracle/make_inlet_fixtures.py): marching squares at 0.5 finds exactly
+    the two edges of the nozzle wall, both pass the 5 % area filter; FFT low-pass + RDP leave small polygons; the
+    two P1 Poisson profiles carry the flow rates ratio and 1 - ratio; the pixel-grid solver bounds the result."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import inlet_contours as IC, inlet_image as II
+    f = os.path.join(ROOT, "tests", "golden", f"inlet_{name}.png")
+    gray = IC.load_image(f)
+    raw = IC.find_contours(gray, 0.5)
+    cs = IC.get_contours(gray)
+    assert len(raw) == 2 and len(cs) == 2
+    for c in raw:
+        assert np.allclose(c[0], c[-1]) and len(c) > 500                       # closed, one point per crossed edge
+        on_grid = np.isclose(c % 1.0, 0.0) | np.isclose(c % 1.0, 1.0)
+        assert np.all(on_grid.any(axis=1))                                      # every point lies on a grid edge
+    assert np.abs(cs[0]).max() <= 0.5 and np.abs(cs[1]).max() < np.abs(cs[0]).max()   # contours[0] is the outer one
+    ratio = 0.3
+    P = IC.solve_inlet_profiles(f, ratio)
+    assert 5 <= len(P.contour_inner) <= 200 and 5 <= len(P.contour_outer) <= 200
+    assert P.mesh_lc[0] == pytest.approx(0.05 * min(np.ptp(P.contour_inner[:, 0]), np.ptp(P.contour_inner[:, 1])))
+    band = 1.0 - P.area_1 - P.area_2
+    assert 0.05 < band < 0.3 and P.area_1 < P.area_2
+    assert P.inner.integral() == pytest.approx(ratio, rel=1e-12) and P.outer.integral() == pytest.approx(1 - ratio, rel=1e-12)
+    # sanity bound: the older pixel-grid restatement (connected components + 5-point Poisson)
+    D = II.solve_inlet_profiles(f, ratio)
+    assert abs(P.area_1 - D.area_1) < 0.01 * D.area_1 + 2e-3 and abs(P.area_2 - D.area_2) < 0.01 * D.area_2
+    assert abs(P.inner.u.max() - D.u1.max()) < 0.05 * D.u1.max() and abs(P.outer.u.max() - D.u2.max()) < 0.06 * D.u2.max()
+    # evaluation: zero in the band and outside its own region, region map consistent with the pixel one
+    rng = np.random.default_rng(0)
+    y, z = rng.uniform(-0.49, 0.49, 400), rng.uniform(-0.49, 0.49, 400)
+    reg = P.region_at(y, z)
+    x = np.stack([np.zeros(400), y, z], axis=1)
+    assert np.all(P.profile_1(x)[reg != 1] == 0) and np.all(P.profile_2(x)[reg != 2] == 0)
+    assert (P.profile_1(x)[reg == 1] > 0).mean() > 0.95
+    assert (reg == D.region_at(y, z)).mean() > 0.97
+    m, (mask, g), data = II.channel_from_image(f, ratio, (12, 10, 10))
+    t = m.meta["tags"]
+    assert len(m.find(t["inlet_1"])) > 0 and len(m.find(t["inlet_2"])) > len(m.find(t["inlet_1"]))
+    assert g[0::4].max() > 1.0 and np.all(g[1::4] == 0)
+
+
+def test_marching_squares_rdp_and_fft_known_answers():
+    from stabilized_navier_stokes_flow_fenicsx_amd import inlet_contours as IC
+    # a disc of radius 0.3 sampled on a 200 x 200 image: one closed contour, radius recovered to sub-pixel accuracy
+    n = 200
+    yy, xx = np.mgrid[0:n, 0:n]
+    r = np.hypot(xx - 99.5, yy - 99.5)
+    img = np.clip((0.3 * n - r) / 2.0 + 0.5, 0.0, 1.0)                           # linear ramp across the edge
+    cs = IC.find_contours(img, 0.5)
+    assert len(cs) == 1 and np.allclose(cs[0][0], cs[0][-1])
+    rad = np.hypot(cs[0][:, 0] - 99.5, cs[0][:, 1] - 99.5)
+    assert np.abs(rad - 0.3 * n).max() < 0.02
+    # saddle cell: the two LOW corners are connected (two separate high blobs)
+    s = np.zeros((4, 4)); s[1, 1] = s[2, 2] = 1.0
+    assert len(IC.find_contours(s, 0.5)) == 2
+    # RDP keeps the corners of a densely sampled square, nothing else
+    sq = np.concatenate([np.linspace([0, 0], [1, 0], 50, endpoint=False), np.linspace([1, 0], [1, 1], 50, endpoint=False),
+                         np.linspace([1, 1], [0, 1], 50, endpoint=False), np.linspace([0, 1], [0, 0], 51)])
+    out = IC.rdp(sq, 1e-6)
+    assert len(out) == 5 and np.allclose(out[0], out[-1])
+    # the low-pass keeps a circle (frequency 1/N) and removes a ripple above the cutoff
+    N = 400
+    t = 2 * np.pi * np.arange(N + 1) / N
+    c = np.stack([0.3 * np.sin(t) + 0.01 * np.sin(80 * t), 0.3 * np.cos(t) + 0.01 * np.cos(80 * t)], axis=1)
+    poly, lc = IC.optimize_contour(c, cutoff=0.12, epsilon=0.0005)
+    assert np.abs(np.hypot(poly[:, 0], poly[:, 1]) - 0.3).max() < 5e-3 and lc == pytest.approx(0.05 * 0.6, rel=0.02)
+    # P1 Poisson on the unit disc: u = p (R^2 - r^2) / 4, mean = p R^2 / 8
+    ang = 2 * np.pi * np.arange(120) / 120
+    disc = 0.4 * np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    pts, tris, bnd = IC.mesh_region(disc, None, 0.03)
+    u, area, avg = IC.solve_velocity_field(pts, tris, bnd)
+    assert area == pytest.approx(np.pi * 0.16, rel=2e-3) and avg == pytest.approx(10 * 0.16 / 8, rel=0.02)
+    assert u.max() == pytest.approx(10 * 0.16 / 4, rel=0.02)
