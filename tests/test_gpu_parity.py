@@ -950,3 +950,75 @@ def test_config4_full_size_channel_newton(gpu):
     ux_out = W[(nx) * sx:(nx + 1) * sx, 0].reshape(ny + 1, nz + 1)
     assert ux_out.max() / Q[-1] > 1.5                                                      # developing towards 2.0963
     P.close()
+
+
+def test_streamtrace_pipeline_from_the_output_files(gpu, tmp_path, monkeypatch):
+    """The reference's post-processing chain end to end (InletBatchScript.py:39-76): solve with an inlet image,
+    save XDMF + HDF5, then for_and_rev_streamtrace re-reads the velocity file (streamtrace.py:590), traces the inner
+    inlet mesh forward, bounds the arrivals by the alpha shape + 20 % blur, traces N x N seeds back and keeps those
+    that end inside the inner inlet contour."""
+    import os
+    from conftest import ROOT
+    from stabilized_navier_stokes_flow_fenicsx_amd import drivers as D, streamtrace as ST
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("InletImages", exist_ok=True)
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "inlet_asym_offset.png"), "InletImages/asym.png")
+    r = D.navier_stokes_channel_main(["NavierStokesChannelFlow.py", "5", "./InletImages/asym.png", "0.4", "0.1"])
+    assert r["newton"].reason > 0
+    folder = tmp_path / "noether_data" / "NSChannelFlow_RE5_MeshLC01_asym"
+    assert (folder / "Re5ChannelVelocity.h5").exists()
+    out = ST.for_and_rev_streamtrace_files(12, str(tmp_path / "InletImages" / "asym.png"), 5, str(folder), out_dir=str(tmp_path))
+    fwd, rev = out["forward"], out["reverse"]
+    # the inner mesh's boundary nodes sit on the nozzle wall (zero velocity: they stop at once, as in the reference);
+    # the interior ones leave the nozzle and most of them reach x = 3.7 within t = 20
+    assert (fwd["pos"][:, 0] > 0.5).mean() > 0.6 and (fwd["status"] == 2).mean() > 0.5
+    lo_y, hi_y, lo_z, hi_z = out["bounds"]
+    arr = fwd["pos"][fwd["pos"][:, 0] > 0.5]
+    assert lo_y < arr[:, 1].min() and hi_y > arr[:, 1].max() and lo_z < arr[:, 2].min() and hi_z > arr[:, 2].max()
+    assert out["rev_seeds"].shape == (144, 3) and np.all(out["rev_seeds"][:, 0] == 3.9)
+    fo = out["final_output"]
+    assert 10 <= len(fo) <= 144 and fo.shape[1] == 2
+    assert np.loadtxt(tmp_path / "final_output.csv", delimiter=",").shape == fo.shape
+    # the kept seeds are the ones whose backward trace ends inside the inner contour, near the inlet
+    ended = rev["pos"][:, 0] < 0.5
+    assert ended.sum() >= len(fo)
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_fgmres_under_the_partitioned_hierarchy(gpu, nranks):
+    """FGMRES(30) with the distributed AMG preconditioner on a 110 k-tet duct over 2 and 4 team ranks: converges like
+    the single-GPU run (about twice BiCGStab's iteration count: one preconditioner application per iteration
+    instead of two), same fields.  (Round 1 logged 10 000-iteration stalls of FGMRES with an over-damped smoother.)"""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    m = M.duct_mesh((72, 16, 16), 4.0, jitter=0.1)
+    assert m.num_tets >= 100_000
+    mask, g = B.duct_bcs(m).flatten()
+    Ps = gpu(m, (mask, g), reynolds=50.0, ksp_type="fgmres")
+    Us, rs = Ps.stokes_solve()
+    ws, ns = Ps.newton_solve(Us.clone())
+    Ps.close()
+    assert rs.reason > 0 and ns.reason > 0
+    owner = PT.rcb_partition(m.points, nranks)
+    team = Team(nranks)
+
+    def work(rank, team):
+        part = PT.build_local_part(m, mask, g, owner, rank, nranks)
+        P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=50.0, ksp_type="fgmres", part=part, group=team,
+                ksp_max_it=500)
+        U, r = P.stokes_solve()
+        w, n = P.newton_solve(U.clone())
+        out = (part, w.cpu().numpy(), r, n)
+        P.close()
+        return out
+
+    outs = team.run(work)
+    team.close()
+    wg = np.zeros(m.num_dofs)
+    for part, w, r, n in outs:
+        gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
+        wg[gd] = w[:4 * part.n_owned]
+        assert r.reason > 0 and n.reason > 0
+        assert r.its <= rs.its + 10 and n.ksp_its <= ns.ksp_its + 30
+    assert rel(wg, ws.cpu().numpy()) < 1e-7

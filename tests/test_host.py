@@ -501,3 +501,42 @@ def test_marching_squares_rdp_and_fft_known_answers():
     u, area, avg = IC.solve_velocity_field(pts, tris, bnd)
     assert area == pytest.approx(np.pi * 0.16, rel=2e-3) and avg == pytest.approx(10 * 0.16 / 8, rel=0.02)
     assert u.max() == pytest.approx(10 * 0.16 / 4, rel=0.02)
+
+
+def test_streamtrace_postprocessing_alpha_shape_blur_and_contour_filter():
+    """expand_streamtace / find_seed_end / update_contour of NavierStokes/streamtrace.py:132-143,292-343,536-553."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import streamtrace as ST
+    rng = np.random.default_rng(3)
+    # alpha = 0.2 on a unit-scale cloud: all but a few flat hull slivers have circumradius < 5 -> ~ the convex hull
+    p = rng.uniform(-0.2, 0.3, size=(400, 2))
+    ring = ST.alpha_shape_exterior(p, 0.2)
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(p)
+    ring_area = 0.5 * abs(np.sum(ring[:-1, 0] * ring[1:, 1] - ring[1:, 0] * ring[:-1, 1]))
+    assert np.allclose(ring[0], ring[-1]) and len(ring) - 1 >= len(hull.vertices)
+    assert ring_area == pytest.approx(hull.volume, rel=5e-3) and np.allclose(ring.min(0), p.min(0)) and np.allclose(ring.max(0), p.max(0))
+    # a large alpha carves the concave corner out of an L-shaped cloud
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 21), np.linspace(0, 1, 21)), -1).reshape(-1, 2)
+    L = g[~((g[:, 0] > 0.5) & (g[:, 1] > 0.5))]
+    r20 = ST.alpha_shape_exterior(L, 20.0 / 1.0)                    # circumradius < 0.05: only the small lattice cells
+    area = 0.5 * abs(np.sum(r20[:-1, 0] * r20[1:, 1] - r20[1:, 0] * r20[:-1, 1]))
+    assert area == pytest.approx(0.75, abs=0.03)
+    # blur: straddling zero -> both ends pushed outwards by 20 %
+    lo_y, hi_y, lo_z, hi_z = ST.expand_streamtace(p[:, 0], p[:, 1])
+    assert lo_y == pytest.approx(1.2 * p[:, 0].min()) and hi_y == pytest.approx(1.2 * p[:, 0].max())
+    assert lo_z == pytest.approx(1.2 * p[:, 1].min()) and hi_z == pytest.approx(1.2 * p[:, 1].max())
+    # not straddling zero: min * (1 - 0.2), max * (1 + 0.2), literally as the reference computes it (:316-321)
+    q = rng.uniform(0.1, 0.3, size=(300, 2))
+    a0, a1, b0, b1 = ST.expand_streamtace(q[:, 0], -q[:, 1])
+    assert a0 == pytest.approx(0.8 * q[:, 0].min()) and a1 == pytest.approx(1.2 * q[:, 0].max())
+    zs = np.sort(-q[:, 1])
+    # all-negative axis: both formulas move the touched vertex TOWARDS zero, so the next vertices take over
+    assert zs[0] < b0 <= 0.8 * zs[0] + 1e-12 and 1.2 * zs[-1] - 1e-12 <= b1 < zs[-1]
+    # reverse-trace filter: seeds whose end point lies inside the inner contour
+    contour = np.array([[0, -0.2, -0.2], [0, 0.2, -0.2], [0, 0.2, 0.2], [0, -0.2, 0.2]], dtype=float)
+    seeds = ST.make_rev_streamtrace_seeds(-0.4, 0.4, -0.4, 0.4, 5)
+    ends_y, ends_z = seeds[:, 1] * 0.9, seeds[:, 2] * 0.9
+    out = ST.find_seed_end(ends_y, ends_z, seeds, contour)
+    assert out.shape == (9, 2) and np.abs(out).max() <= 0.2 + 1e-12
+    c = ST.update_contour(os.path.join(ROOT, "tests", "golden", "inlet_PlusF_final.png"))
+    assert c.shape[1] == 3 and np.all(c[:, 0] == 0) and 5 < len(c) < 200 and np.abs(c[:, 1:]).max() < 0.5
