@@ -1121,8 +1121,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x);
 // First level (>= 1) small enough that its kernels are launch-bound rather than bandwidth-bound: it and everything
 // below run as one graph.  10 M tets: level 2 (36 k rows; level 1 has 218 k rows = 46 us per sweep); 1 M tets: level 1.
 inline int serial_graph_level(const sns_ctx* h) {
+    static const int max_rows = std::getenv("SNS_GRAPH_ROWS") ? std::atoi(std::getenv("SNS_GRAPH_ROWS")) : 150000;
     for (int l = 1; l < (int)h->levels.size(); ++l)
-        if (h->levels[l].n <= 150000) return l;
+        if (h->levels[l].n <= max_rows) return l;
     return 0;
 }
 
@@ -1429,7 +1430,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             const int32_t rows = h->n_owned;
             const int gs = (rows + 31) / 32;
             SNS_TRY(op_apply_dot(h, ph, v, rhat));        // v = A ph with the fused partial sums of <rhat, v>
-            SNS_TRY(reduce_to(h, gs + h->bnd_dot_blocks, 1, red));
+            SNS_TRY(reduce_to(h, 4 * (gs + h->bnd_dot_blocks), 1, red));     // one partial per wave
             hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
             return SNS_OK;
         };
@@ -1883,7 +1884,7 @@ static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_te
         SNS_TRY(dev_upload(&h->levels[0].free_mask, fm, nullptr));
     }
     // per-block partial sums: vector kernels use <= 2048 blocks x <= 8 sums, the fused SpMV+dot one block per 32 rows
-    SNS_TRY(dev_alloc(&h->partial, std::max<size_t>((size_t)65536 * 8, (size_t)n_nodes / 16 + 128)));
+    SNS_TRY(dev_alloc(&h->partial, std::max<size_t>((size_t)65536 * 8, (size_t)n_nodes / 4 + 512)));
     SNS_TRY(dev_alloc(&h->partial2, (size_t)4096 * 8));
     SNS_TRY(dev_alloc(&h->d_scal, 256));
     SNS_TRY(dev_alloc(&h->d_sing, 1));

@@ -1410,12 +1410,11 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
             y[4 * (int64_t)row + r] = acc;
             pr = acc * pre_v;
         }
-        __shared__ double red[4];
+        // one partial sum per WAVE (no workgroup barrier at the end of the kernel: a wave retires as soon as its
+        // 8 rows are done); the host reduces 4 * gridDim.x entries
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
-        if (lane == 0) red[tid >> 6] = pr;
-        __syncthreads();
-        if (tid == 0) partial[blockIdx.x + partial_off] = red[0] + red[1] + red[2] + red[3];
+        if (lane == 0) partial[4 * ((int64_t)blockIdx.x + partial_off) + (tid >> 6)] = pr;
     }
 }
 
