@@ -75,7 +75,7 @@ def cpu_baseline(mesh, mask, g, U, Re, maxit=200):
                       f"||F|| {f0:.2e} -> {f1:.2e}{bound}"}
 
 
-def pmc_traffic(kernel_substr="k_spmv<2, 1"):
+def pmc_traffic(kernel_substr):
     """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc CSVs
     (profiles/*pmc*counter_collection.csv), corrected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE is in KiB and reads half the bytes of a wide streaming read on gfx950 (x2);
@@ -249,25 +249,46 @@ def main():
         all_f64 = {"value": round(n_dof_global / (ms64 * 1e-3) / 1e6, 3), "unit": "M-DOF/s", "ms_per_step": round(ms64, 3),
                    "ksp_its": [b for _, b, _ in log64]}
         P.set_options(amg_f32_matrix=fmt0)
-    # dominant kernel: the level-0 block-Jacobi sweep of the AMG cycle (3 of the 5 fine-level matrix passes
-    # per preconditioner application).  Algorithmic bytes per launch:
-    #   per nonzero block: values (64 B as the preconditioner's fp32 copy, 128 B in fp64) + 4 B column index
-    #   per block row: 4 rowptr + 32 x + 32 b + 128 Dinv + 32 y = 228 B
-    #   fp16 copy: 32 B values + 4 B index per block, + 16 B of row scales per block row
+    # The four fine-level matrix passes of a BiCGStab iteration (2 x Jacobi sweep + 2 x residual of the two V-cycles on the
+    # preconditioner's matrix copy, y = Ax and y = Ax + <r^, y> on the fp64 operator) are 60 % of a step, each 22-27 % of
+    # the SpMV time.  Algorithmic bytes per launch:
+    #   per nonzero block: values + 4 B column index -- 128 B fp64 operator, 64 B fp32 copy, 32 B fp16 copy
+    #   per block row:     4 rowptr + 32 per vector touched (x, b, y, dot weight) + 128 Dinv (Jacobi) + 16 row scales (fp16)
     fmt = int(P.options.amg_f32_matrix)
-    kname = {0: "k_spmv<SPMV_JACOBI,FINE>", 1: "k_spmv_lp<SPMV_JACOBI,FINE,fp32>", 2: "k_spmv_lp<SPMV_JACOBI,FINE,fp16>"}[fmt]
-    jac_ms, jac_calls = kt["jacobi"]
-    alg_bytes = {0: 132.0, 1: 68.0, 2: 36.0}[fmt] * s["nnzb"] + (228.0 + (16.0 if fmt == 2 else 0.0)) * s["n_owned"]
+    lp = {0: ("k_spmv<{m}, 1, 1, 0>", 132.0, 0.0), 1: ("k_spmv_lp<{m}, 1, 0, 1>", 68.0, 0.0), 2: ("k_spmv_lp<{m}, 1, 0, 2>", 36.0, 16.0)}[fmt]
+    nb, nr = float(s["nnzb"]), float(s["n_owned"])
+    kinfo = {
+        "jacobi": (lp[0].format(m=2), lp[1] * nb + (4 + 32 * 3 + 128 + lp[2]) * nr, "AMG fine-level block-Jacobi sweep"),
+        "b_minus_ax": (lp[0].format(m=1), lp[1] * nb + (4 + 32 * 3 + lp[2]) * nr, "AMG fine-level residual r = b - Ax"),
+        "ax": ("k_spmv<0, 1, 1, 0>", 132.0 * nb + (4 + 32 * 2) * nr, "Krylov operator y = Ax (fp64)"),
+        "ax_dot": ("k_spmv<3, 1, 1, 0>", 132.0 * nb + (4 + 32 * 3) * nr, "Krylov operator y = Ax + <r^, y> (fp64)"),
+    }
+    per_kernel = {}
+    for key, (kname_k, bytes_k, what) in kinfo.items():
+        ms_k, calls_k = kt[key]
+        if calls_k > 0:
+            avg = ms_k / calls_k
+            ach = bytes_k / (avg * 1e-3) / 1e9
+            per_kernel[key] = {"kernel": kname_k, "what": what, "avg_launch_ms": round(avg, 5), "launches": int(calls_k),
+                               "total_ms": round(ms_k, 2), "algorithmic_bytes_per_launch": bytes_k,
+                               "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": pmc_traffic(kname_k) if cfg == 5 else None}
     roofline = None
-    if jac_calls > 0:
-        avg_ms = jac_ms / jac_calls
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic({0: "k_spmv<2, 1", 1: "k_spmv_lp<2, 1, 0, 1>", 2: "k_spmv_lp<2, 1, 0, 2>"}[fmt])
-                               if cfg == 5 else None,
-                    "kernel": kname, "avg_launch_ms": round(avg_ms, 5),
-                    "launches": int(jac_calls), "algorithmic_bytes_per_launch": alg_bytes,
+    if per_kernel:
+        dom = max(per_kernel, key=lambda k_: per_kernel[k_]["total_ms"])       # dominant = largest total time, live
+        d = per_kernel[dom]
+        fam_bytes = sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in per_kernel.values())
+        fam_ms = sum(v["total_ms"] for v in per_kernel.values())
+        roofline = {"bound": "hbm", "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+                    "traffic": d["traffic"], "kernel": d["kernel"], "what": d["what"],
+                    "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                    "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                    "selection": "the fine-level SpMV kernel with the largest total time inside the timed region "
+                                 "(HIP events around every launch); the four are within a few % of each other",
+                    "fine_level_spmv_kernels": per_kernel,
+                    "fine_level_spmv_family": {"share_of_step": round(fam_ms / (ms_per_step * args.steps), 3),
+                                               "achieved": round(fam_bytes / (fam_ms * 1e-3) / 1e9, 1),
+                                               "frac": round(fam_bytes / (fam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                     "assembly_kernels": {"avg_ms": round(asm_ms, 4), "algorithmic_bytes": asm_bytes,
                                          "achieved": round(asm_bytes / (asm_ms * 1e-3) / 1e9, 1),
                                          "frac": round(asm_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -283,9 +304,7 @@ def main():
                                                           "achieved_tflops": round(17680.0 * s["n_tets"] / (asm_ms * 1e-3) / 1e12, 2),
                                                           "peak_tflops": 78.6,
                                                           "frac": round(17680.0 * s["n_tets"] / (asm_ms * 1e-3) / 1e12 / 78.6, 4)}
-                                                         if P.options.assembly_fused else None)},
-                    "other_fine_spmv": {k: {"avg_ms": round(v[0] / v[1], 5), "launches": int(v[1])}
-                                        for k, v in kt.items() if v[1] > 0 and k != "jacobi"}}
+                                                         if P.options.assembly_fused else None)}}
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -167,7 +167,7 @@ int sync_stream(sns_ctx* h) {
     return SNS_OK;
 }
 
-void time_begin(sns_ctx* h, int mode) {
+void time_begin(sns_ctx* h, int mode, hipStream_t st = nullptr) {
     if (!h->time_kernels) return;
     if (h->ev_used == h->ev_pool.size()) {
         std::array<hipEvent_t, 2> p;
@@ -177,11 +177,11 @@ void time_begin(sns_ctx* h, int mode) {
         h->ev_mode.push_back(0);
     }
     h->ev_mode[h->ev_used] = mode;
-    (void)hipEventRecord(h->ev_pool[h->ev_used][0], h->stream);
+    (void)hipEventRecord(h->ev_pool[h->ev_used][0], st ? st : h->stream);
 }
-void time_end(sns_ctx* h) {
+void time_end(sns_ctx* h, hipStream_t st = nullptr) {
     if (!h->time_kernels) return;
-    (void)hipEventRecord(h->ev_pool[h->ev_used][1], h->stream);
+    (void)hipEventRecord(h->ev_pool[h->ev_used][1], st ? st : h->stream);
     ++h->ev_used;
 }
 // resolve recorded event pairs (stream must be idle)
@@ -241,9 +241,6 @@ int halo_exchange(sns_ctx* h, double* x) { return exchange_level(h, 0, x); }
 // Per-launch timing of the level-0 SpMV family (bench.py roofline leg): event pairs are
 // recorded around every fine-level launch while h->time_kernels is set and resolved after
 // the solve has synchronised.
-struct EvPair { hipEvent_t a, b; int mode; };
-void time_begin(sns_ctx* h, int mode);
-void time_end(sns_ctx* h);
 
 // Multi-GPU, level 0: a pass is either over every row (split 0), over the interior rows only (1: rows with a ghost
 // column, flagged in h->bnd_flag, are skipped) or over the boundary rows listed in h->bnd_rows (2).
@@ -263,8 +260,10 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
     const int grid = (rows + 31) / 32;
     if (grid == 0) return;
     if (fine && sp.mode == 1) {
+        time_begin(h, MODE, st);                      // multi-GPU: the interior pass is the bulk of a split launch
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
                            b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, h->bnd_flag, sp.partial_off);
+        time_end(h, st);
     } else if (fine && sp.mode == 2) {
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 2>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
                            b, L.dinv, omega, dotw, h->partial, h->bnd_rows, (const uint8_t*)nullptr, sp.partial_off);
@@ -297,7 +296,9 @@ void launch_lp_fmt(sns_ctx* h, const Level& L, int32_t rows, const double* x, do
     hipStream_t st = sp.stream ? sp.stream : h->stream;
     const bool fine = (&L == &h->levels[0]);
     if (fine && sp.mode == 1) {
+        time_begin(h, MODE, st);
         launch_lp<MODE, 1, 1, FMT>(h, L, rows, st, x, y, b, omega);
+        time_end(h, st);
     } else if (fine && sp.mode == 2) {
         launch_lp<MODE, 1, 2, FMT>(h, L, h->n_bnd, st, x, y, b, omega);
     } else if (fine) {

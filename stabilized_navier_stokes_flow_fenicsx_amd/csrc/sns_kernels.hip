@@ -1514,8 +1514,12 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);       // FMT 1
     const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);         // FMT 2: pairs
     int32_t k = s;
+    // the block ids of the NEXT step are requested one step ahead: index -> x gather is a dependent chain of two
+    // memory round trips per step otherwise (matters on the coarse levels, whose rows have ~27 blocks = 7 steps)
+    int32_t cnext = (k + 3 < e) ? colind[k + r] : 0;
     for (; k + 3 < e; k += 4) {
-        const int32_t cme = colind[k + r];
+        const int32_t cme = cnext;
+        if (k + 7 < e) cnext = colind[k + 4 + r];
         const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];                     // the whole x block of column (k + r)
         if (FMT == 1) {
