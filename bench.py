@@ -253,12 +253,14 @@ def main():
     # preconditioner's matrix copy, y = Ax and y = Ax + <r^, y> on the fp64 operator) are 60 % of a step, each 22-27 % of
     # the SpMV time.  Algorithmic bytes per launch:
     #   per nonzero block: values + 4 B column index -- 128 B fp64 operator, 64 B fp32 copy, 32 B fp16 copy
-    #   per block row:     4 rowptr + 32 per vector touched (x, b, y, dot weight) + 128 Dinv (Jacobi) + 16 row scales (fp16)
+    #   per block row:     4 rowptr + 32 per vector touched (x, b, y, dot weight) + D^-1 (Jacobi: 128 B fp64, 64 B as the
+    #                      fp32 copy the low-precision sweeps read) + 16 row scales (fp16)
     fmt = int(P.options.amg_f32_matrix)
     lp = {0: ("k_spmv<{m}, 1, 1, 0>", 132.0, 0.0), 1: ("k_spmv_lp<{m}, 1, 0, 1>", 68.0, 0.0), 2: ("k_spmv_lp<{m}, 1, 0, 2>", 36.0, 16.0)}[fmt]
     nb, nr = float(s["nnzb"]), float(s["n_owned"])
     kinfo = {
-        "jacobi": (lp[0].format(m=2), lp[1] * nb + (4 + 32 * 3 + 128 + lp[2]) * nr, "AMG fine-level block-Jacobi sweep"),
+        "jacobi": (lp[0].format(m=2), lp[1] * nb + (4 + 32 * 3 + (128 if fmt == 0 else 64) + lp[2]) * nr,
+                   "AMG fine-level block-Jacobi sweep"),
         "b_minus_ax": (lp[0].format(m=1), lp[1] * nb + (4 + 32 * 3 + lp[2]) * nr, "AMG fine-level residual r = b - Ax"),
         "ax": ("k_spmv<0, 1, 1, 0>", 132.0 * nb + (4 + 32 * 2) * nr, "Krylov operator y = Ax (fp64)"),
         "ax_dot": ("k_spmv<3, 1, 1, 0>", 132.0 * nb + (4 + 32 * 3) * nr, "Krylov operator y = Ax + <r^, y> (fp64)"),

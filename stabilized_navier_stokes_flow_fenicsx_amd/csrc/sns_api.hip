@@ -287,7 +287,7 @@ void launch_lp(sns_ctx* h, const Level& L, int32_t rows, hipStream_t st, const d
     if (grid == 0) return;
     const void* vals = FMT == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
     hipLaunchKernelGGL((k_spmv_lp<MODE, FINE, SPLIT, FMT>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
-                       L.scale16, x, y, b, L.dinv, omega, SPLIT == 2 ? h->bnd_rows : (const int32_t*)nullptr,
+                       L.scale16, x, y, b, L.dinv32, omega, SPLIT == 2 ? h->bnd_rows : (const int32_t*)nullptr,
                        SPLIT == 1 ? h->bnd_flag : (const uint8_t*)nullptr);
 }
 template <int MODE, int FMT>
@@ -1036,6 +1036,10 @@ int pc_setup(sns_ctx* h) {
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         L.omega = h->opt.amg_omega;
         if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
+            if (!L.dinv32) SNS_TRY(dev_alloc(&L.dinv32, (size_t)16 * std::max(1, L.n)));
+            if (rows > 0)
+                hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(16 * (int64_t)rows)), dim3(256), 0, h->stream, 16 * (int64_t)rows,
+                                   L.dinv, L.dinv32);
             if (h->opt.amg_f32_matrix == 2) {
                 if (!L.vals16) {
                     uint2* v16 = nullptr;
@@ -1934,7 +1938,7 @@ int sns_destroy(sns_handle h) {
     fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->gext); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
-        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16);
+        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);

@@ -54,6 +54,7 @@ struct Level {
     float* vals32 = nullptr;             // fp32 copy of vals for the preconditioner passes (amg_f32_matrix)
     void* vals16 = nullptr;              // fp16 copy, row-scaled (amg_f32_matrix = 2): 4 halfs per block row
     float* scale16 = nullptr;            // its scales, one per dof row
+    float* dinv32 = nullptr;             // fp32 copy of dinv for the low-precision Jacobi sweeps
     // to the next coarser level
     int32_t nc = 0;
     int32_t* agg = nullptr;              // n

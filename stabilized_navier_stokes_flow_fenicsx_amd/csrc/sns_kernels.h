@@ -55,7 +55,7 @@ __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* col
                        int partial_off);
 template <int MODE, int FINE, int SPLIT, int FMT>
 __global__ void k_spmv_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
-                          const float* scale, const double* x, double* y, const double* bvec, const double* dinv,
+                          const float* scale, const double* x, double* y, const double* bvec, const float* dinv32,
                           double omega, const int32_t* row_list, const uint8_t* skip);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_cvt_h16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale);

@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
                                                  const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
                                                  const float* __restrict__ scale, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
-                                                 const double* __restrict__ dinv, double omega,
+                                                 const float* __restrict__ dinv, double omega,
                                                  const int32_t* __restrict__ row_list,
                                                  const uint8_t* __restrict__ skip) {
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -1501,15 +1501,13 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
     // the row's b, x and D^-1 entries are requested BEFORE the block loop, so their latency hides behind it
     double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
-    double2 pre_d01 = make_double2(0.0, 0.0), pre_d23 = pre_d01;
+    float4 pre_d = make_float4(0.f, 0.f, 0.f, 0.f);      // row r of the node's D^-1 (fp32 copy: part of the smoother's matrix data)
     if (FMT == 2 && live) sc = (double)scale[4 * (int64_t)row + r];
     if (MODE == SPMV_B_MINUS_AX && live) pre_b = bvec[4 * (int64_t)row + r];
     if (MODE == SPMV_JACOBI && live) {
         pre_b = bvec[4 * (int64_t)row + r];
         pre_x = x[4 * (int64_t)row + r];
-        const double2* D2 = reinterpret_cast<const double2*>(dinv + 16 * (int64_t)row + 4 * r);
-        pre_d01 = D2[0];
-        pre_d23 = D2[1];
+        pre_d = *reinterpret_cast<const float4*>(dinv + 16 * (int64_t)row + 4 * r);
     }
     const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);       // FMT 1
     const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);         // FMT 2: pairs
@@ -1570,13 +1568,14 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
         const double res = live ? (pre_b - acc) : 0.0;
         const double r0 = quad_bcast<0>(res), r1 = quad_bcast<1>(res), r2 = quad_bcast<2>(res), r3 = quad_bcast<3>(res);
         if (live)
-            y[4 * (int64_t)row + r] = pre_x + omega * (pre_d01.x * r0 + pre_d01.y * r1 + pre_d23.x * r2 + pre_d23.y * r3);
+            y[4 * (int64_t)row + r] = pre_x + omega * ((double)pre_d.x * r0 + (double)pre_d.y * r1 + (double)pre_d.z * r2 +
+                                                        (double)pre_d.w * r3);
     }
 }
 #define SNS_INST_LP(M, F, S, T)                                                                                    \
     template __global__ void k_spmv_lp<M, F, S, T>(int32_t, const int32_t*, const int32_t*, const void*,              \
                                                    const float*, const double*, double*, const double*,              \
-                                                   const double*, double, const int32_t*, const uint8_t*);
+                                                   const float*, double, const int32_t*, const uint8_t*);
 #define SNS_INST_LP_FMT(T)                \
     SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, T) \
     SNS_INST_LP(SPMV_B_MINUS_AX, 1, 1, T) \
