@@ -160,3 +160,71 @@ def test_dfg2d_mesh_geometry_tags_and_msh_round_trip(tmp_path):
     assert np.bincount(r.facet_tags).tolist() == np.bincount(m.facet_tags).tolist()
     c = M2.rectangle_mesh(4)
     assert c.tris[:2].tolist() == [[0, 1, 6], [0, 5, 6]]                      # create_rectangle, diagonal "right"
+
+
+def test_read_msh41_2d_with_physical_curves(tmp_path):
+    """gmsh 4.1 ASCII as ``gmsh dfg_pillar_2D.geo -2 -format msh4`` writes it: physical groups arrive through the
+    entity table ($Entities: curve -> physical tag), elements are grouped per entity (DFG_2D_Validation.py:28)."""
+    txt = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$PhysicalNames
+3
+1 2 "inlet"
+1 4 "walls"
+2 1 "fluid"
+$EndPhysicalNames
+$Entities
+4 4 1 0
+1 0 0 0 0
+2 1 0 0 0
+3 1 1 0 0
+4 0 1 0 0
+1 0 0 0 1 0 0 1 4 2 1 -2
+2 1 0 0 1 1 0 1 4 2 2 -3
+3 0 1 0 1 1 0 1 4 2 3 -4
+4 0 0 0 0 1 0 1 2 2 4 -1
+1 0 0 0 1 1 0 1 1 4 1 2 3 4
+$EndEntities
+$Nodes
+2 5 1 5
+0 1 0 4
+1
+2
+3
+4
+0 0 0
+1 0 0
+1 1 0
+0 1 0
+2 1 0 1
+5
+0.5 0.5 0
+$EndNodes
+$Elements
+5 8 1 8
+1 1 1 1
+1 1 2
+1 2 1 1
+2 2 3
+1 3 1 1
+3 3 4
+1 4 1 1
+4 4 1
+2 1 2 4
+5 1 2 5
+6 2 3 5
+7 3 4 5
+8 4 1 5
+$EndElements
+"""
+    f = tmp_path / "sq.msh"
+    f.write_text(txt)
+    m = M2.read_msh_2d(str(f), reorder=False)
+    assert m.num_nodes == 5 and m.num_cells == 4 and m.points.shape == (5, 2)
+    assert sorted(m.facet_tags.tolist()) == [2, 4, 4, 4]                       # curve 4 carries "inlet" (2), the rest "walls"
+    inlet = m.facets[m.find(2)][0]
+    assert set(inlet.tolist()) == {3, 0}                                       # nodes 4-1 of the file, zero-based
+    a = m.points[m.tris]
+    area = 0.5 * np.abs((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    assert area.sum() == pytest.approx(1.0)
