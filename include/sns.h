@@ -198,7 +198,10 @@ int sns_spmv(sns_handle h, const double* x_dev, double* y_dev);
 int sns_pc_setup(sns_handle h);
 int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
 /* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
- * guess on entry.  rnorm = final true-residual 2-norm.                        */
+ * guess on entry.  rnorm = final true-residual 2-norm.  A solve that FAILS under
+ * SNS_PC_AMG is retried once from the same guess with every level's block-Jacobi
+ * damping scaled by 0.7 (kept for later solves of the handle); *its counts both
+ * attempts, *reason is the last attempt's.                                     */
 int sns_krylov_solve(sns_handle h, const double* b_dev, double* x_dev,
                      int* its, int* reason, double* rnorm);
 /* solve_stokes_problem (:197-218): assemble + lift + KSP; U_dev receives U.   */

@@ -127,6 +127,7 @@ struct sns_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_x = nullptr, ev_side = nullptr;
     bool no_overlap = false;
+    double damping_backoff = 1.0;                    // < 1 after a failed AMG-preconditioned solve: all level dampings scaled (krylov())
     bool no_windows = false;                         // SNS_NO_WINDOWS: A/B switch for the windowed LDS gathers                          // extra partial-sum blocks of the boundary pass of a split SpMV+dot
     std::unique_ptr<Comm> comm;
     // distributed coarsest level: global dense inverse, replicated on every rank
@@ -1034,7 +1035,7 @@ int pc_setup(sns_ctx* h) {
         }
         if (rows > 0)
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
-        L.omega = h->opt.amg_omega;
+        L.omega = h->opt.amg_omega * h->damping_backoff;
         if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
             if (!L.dinv32) SNS_TRY(dev_alloc(&L.dinv32, (size_t)16 * std::max(1, L.n)));
             if (rows > 0)
@@ -1066,7 +1067,7 @@ int pc_setup(sns_ctx* h) {
                 SNS_TRY(estimate_lambda_max(h, l, &lam));
             const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0;
             L.lambda_max = lam;
-            if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam);
+            if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam) * h->damping_backoff;
             if (fresh && lam > 0.0) {
                 // verify the damping on the dominant mode; back off until a sweep contracts it by >= 10 %
                 for (int trial = 0; trial < 6; ++trial) {
@@ -1696,12 +1697,39 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
     h->ctr_host_syncs = h->ctr_allreduce = h->ctr_exchange = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    int rc;
-    if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
-    else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
-    else if (h->opt.ksp_type == SNS_KSP_TFQMR) rc = tfqmr(h, b, x, its, reason, rnorm);
-    else { set_error("bad ksp_type"); return SNS_E_ARG; }
-    SNS_TRY(rc);
+    // A failed solve under the AMG preconditioner is retried ONCE with every level's block-Jacobi damping scaled by 0.7
+    // (from the same initial guess): the damping estimate (|lambda|max of Dinv A + a growth check on the dominant mode)
+    // is not a bound for a non-symmetric operator, and at cell Reynolds numbers of 5-10 a slightly over-relaxed
+    // smoother is what breaks BiCGStab down (measured: jittered 648 k-tet duct, Re 200: auto damping fails after 218
+    // iterations, 0.7 x converges).  The smaller damping is kept for the later Jacobians of the handle.  Not in the
+    // reference (PETSc reports the failed reason and stops); converging solves never see it.
+    const bool can_retry = h->opt.pc_type == SNS_PC_AMG && h->damping_backoff > 0.4;
+    double* x0 = nullptr;
+    if (can_retry) {
+        SNS_TRY(get_vec(h, 14, &x0));
+        HIP_TRY(hipMemcpyAsync(x0, x, nred_of(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    int its_total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
+        else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
+        else if (h->opt.ksp_type == SNS_KSP_TFQMR) rc = tfqmr(h, b, x, its, reason, rnorm);
+        else { set_error("bad ksp_type"); return SNS_E_ARG; }
+        SNS_TRY(rc);
+        its_total += *its;
+        if (*reason > 0 || !can_retry || attempt == 1) break;
+        h->damping_backoff *= 0.7;
+        if (h->opt.monitor)
+            std::printf("  KSP failed (reason %d after %d iterations): retrying with the smoother damping scaled by %.2f\n",
+                        *reason, *its, h->damping_backoff);
+        for (auto& L : h->levels) {
+            L.omega *= 0.7;
+            if (L.omega_checked > 0.0) L.omega_checked *= 0.7;
+        }
+        HIP_TRY(hipMemcpyAsync(x, x0, nred_of(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    *its = its_total;
     h->last_ctr[0] = h->ctr_host_syncs; h->last_ctr[1] = h->ctr_allreduce; h->last_ctr[2] = h->ctr_exchange;
     SNS_TRY(halo_exchange(h, x));                          // leave the solution's ghost tail current
     HIP_TRY(hipEventRecord(h->ev1, h->stream));

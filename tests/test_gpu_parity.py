@@ -1026,3 +1026,18 @@ def test_fgmres_under_the_partitioned_hierarchy(gpu, nranks):
         assert r.reason > 0 and n.reason > 0
         assert r.its <= rs.its + 10 and n.ksp_its <= ns.ksp_its + 30
     assert rel(wg, ws.cpu().numpy()) < 1e-7
+
+
+def test_damping_backoff_rescues_a_failed_linear_solve(gpu):
+    """At cell Reynolds numbers of 5-10 the automatically chosen block-Jacobi damping can be slightly too large for the
+    non-symmetric Jacobian and BiCGStab breaks down (jittered 648 k-tet duct at Re 200: the first Newton step's solve
+    fails after ~200 iterations).  krylov() retries such a solve once with every level's damping scaled by 0.7 and
+    keeps the smaller damping; the Newton loop then converges as with a hand-set amg_omega = 0.6."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((120, 30, 30), 4.0, jitter=0.2)
+    P = gpu(m, B.duct_bcs(m), reynolds=200.0, ksp_max_it=1500)
+    U, r = P.stokes_solve()
+    w, n = P.newton_solve(U.clone())
+    assert r.reason > 0 and n.reason > 0 and n.its <= 6
+    assert float(P.residual(w, "ns").norm()) < 1e-8
+    P.close()
