@@ -1265,7 +1265,13 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         HIP_TRY(hipMemsetAsync(cur + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(oth + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
     }
-    if (rows > 0) hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+    // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read
+    if (rows > 0) {
+        if (lp_format(h, L) != 0 && L.dinv32)
+            hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, om, cur);
+        else
+            hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+    }
     for (int s = 1; s < nu; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);

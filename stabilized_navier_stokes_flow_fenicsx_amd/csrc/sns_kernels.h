@@ -61,6 +61,7 @@ __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_cvt_h16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
+__global__ void k_bjacobi32(int32_t n, const float* dinv32, const double* r, double omega, double* z);
 __global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);
 __global__ void k_reduce_chunks(int nblocks, int nred, const double* partial, double* out);
 __global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);

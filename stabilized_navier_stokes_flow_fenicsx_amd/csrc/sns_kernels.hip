@@ -1687,6 +1687,20 @@ __global__ __launch_bounds__(256) void k_bjacobi(int32_t n, const double* __rest
     z[4 * i + c] = omega * (D[0] * rr[0] + D[1] * rr[1] + D[2] * rr[2] + D[3] * rr[3]);
 }
 
+// the same with the fp32 copy of D^-1 the low-precision sweeps use (first sweep of a cycle: 128 instead of 192 B per node)
+__global__ __launch_bounds__(256) void k_bjacobi32(int32_t n, const float* __restrict__ dinv,
+                                                   const double* __restrict__ r, double omega,
+                                                   double* __restrict__ z) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int c = (int)(gid & 3);
+    if (i >= n) return;
+    const float4 D = *reinterpret_cast<const float4*>(dinv + 16 * i + 4 * c);
+    const double2* rr = reinterpret_cast<const double2*>(r + 4 * i);
+    const double2 r01 = rr[0], r23 = rr[1];
+    z[4 * i + c] = omega * ((double)D.x * r01.x + (double)D.y * r01.y + (double)D.z * r23.x + (double)D.w * r23.y);
+}
+
 // ============================================================================
 // K4: vector kernels.  Reductions are two-stage and deterministic: each block
 // writes its partial sums to `partial[blockIdx * nred + k]`; k_reduce_final sums
