@@ -427,3 +427,60 @@ def dfg_2d_main(argv=None):
     r = P.last_newton
     P.close()
     return msh, wg, (cd, cl), r
+
+
+def dfg_3d_main(argv=None):
+    """DFG_3D_Validation.py (no arguments: reads ``dfg_pillar_3D.msh`` from the working directory, :73-79): Stokes,
+    NS with nu = 1e-3 (:193) from the Stokes field, traction integral over the obstacle (tag 5) and
+    C = 2 F / (rho Uc^2 Lc), Uc = 0.2, Lc = 0.1 * 0.41 (:344-367), XDMF output (:381-396).  Without the .msh (gmsh is
+    absent offline) the same geometry is meshed by Delaunay (``mesh.dfg_pillar_mesh``; ``builtin[:n]`` as argument picks
+    the resolution h = W/n, default 32)."""
+    from . import functionals as Fn
+    from .solver import solve_navier_stokes
+    argv = sys.argv if argv is None else argv
+    src = argv[1] if len(argv) > 1 else "dfg_pillar_3D.msh"
+    if src.startswith("builtin") or not os.path.exists(src):
+        n = int(src.split(":")[1]) if src.startswith("builtin") and ":" in src else 32
+        msh = M.reorder_for_locality(M.dfg_pillar_mesh(n, lattice="bcc"))[0]
+    else:
+        msh = M.read_msh(src)
+        msh.meta.setdefault("tags", {"inlet": 2, "outlet": 3, "wall": 4, "obstacle": 5})      # :104-109
+        msh.meta.setdefault("width", 0.41)
+    nu = 0.001
+    if _rank() == 0:
+        print(f"Pressure Degrees of Freedom: {msh.num_nodes}", flush=True)
+        print(f"Velocity Degrees of Freedom: {msh.num_nodes}", flush=True)
+    P = _problem(msh, B.dfg_bcs(msh), reynolds=1.0 / nu, ksp_type=snes_ksp_type)
+    U, res = P.stokes_solve()
+    if _rank() == 0:
+        print("Solved Stokes Flow", flush=True)
+    w, u, p = solve_navier_stokes(P, U.clone(), _rank(), continuation=_continuation())
+    wg = _to_global_host(P, w)
+    force = Fn.boundary_traction_force(msh, wg, nu, msh.meta["tags"]["obstacle"])
+    cd, cl = Fn.drag_lift_coefficients(force)
+    if _rank() == 0:
+        print(f"Coefficient of Lift: {cl}", flush=True)
+        print(f"Coefficient of Drag: {cd}", flush=True)
+        write_xdmf("DFGValidationPressureNavierStokes", msh, "Pressure", wg.reshape(-1, 4)[:, 3].copy())
+        write_xdmf("DFGValidationVelocityNavierStokes", msh, "Velocity", wg.reshape(-1, 4)[:, :3].copy())
+    r = P.last_newton
+    P.close()
+    return msh, wg, (cd, cl), r
+
+
+def streamtrace_main(argv=None):
+    """streamtrace.py <img_fname> <solname> <funcname> (:475-491, main :667-689): velocity from ``<solname>.xdmf/.h5``,
+    forward trace of the inner inlet mesh, alpha-shape bound, 50 x 50 reverse seeds, contour filter; writes
+    ``rev_seeds.csv`` and ``final_output.csv`` next to the image (save_figs :497-520; the SVG figures are not drawn)."""
+    from . import streamtrace as ST
+    argv = sys.argv if argv is None else argv
+    if len(argv) != 4:
+        raise ValueError("Usage: script.py <img_fname> <solname> <funcname>")
+    img_fname, solname, funcname = argv[1], argv[2], argv[3]
+    folder, base = os.path.dirname(os.path.abspath(solname)), os.path.basename(solname)
+    if not (base.startswith("Re") and base.endswith("ChannelVelocity")) or funcname != "Velocity":
+        raise ValueError("expected <solname> = .../Re<Re>ChannelVelocity and <funcname> = Velocity")
+    Re = base[len("Re"):-len("ChannelVelocity")]
+    out = ST.for_and_rev_streamtrace_files(50, img_fname, Re, folder, out_dir=os.path.dirname(os.path.abspath(img_fname)))
+    print(f"{len(out['final_output'])} of {len(out['rev_seeds'])} reverse seeds end inside the inner inlet contour", flush=True)
+    return out

@@ -613,20 +613,14 @@ def test_dfg_pillar_benchmark_drag_and_pressure_drop(gpu):
     benchmark, literature C_d 6.05-6.25 (6.185), C_l 0.008-0.010, Delta p 0.165-0.175).  On body-centred-lattice Delaunay
     meshes of the geometry the solver gives C_d 6.318 / 6.262 / 6.236 / 6.196 and Delta p 0.161 / 0.160 / 0.163 / 0.166 at
     h = W/32, W/40, W/50, W/64 (2.1 ... 16.7 M tets, scripts/gpu_dfg3d.py); the coarsest of these runs here."""
-    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, functionals as Fn, mesh as M
-    nu = 0.001
-    m = M.reorder_for_locality(M.dfg_pillar_mesh(32))[0]
-    P = gpu(m, B.dfg_bcs(m), reynolds=1.0 / nu, ksp_max_it=3000)
-    U, r = P.stokes_solve()
-    w, res = P.newton_solve(U.clone())
-    assert r.reason > 0 and res.reason > 0 and res.its <= 6
-    wh = w.cpu().numpy()
-    cd, cl = Fn.drag_lift_coefficients(Fn.boundary_traction_force(m, wh, nu, m.meta["tags"]["obstacle"]))
+    from stabilized_navier_stokes_flow_fenicsx_amd import drivers as D
+    # through the script's own entry point (DFG_3D_Validation.py; "builtin:32" = the gmsh-free mesh of the geometry)
+    m, wh, (cd, cl), res = D.dfg_3d_main(["DFG_3D_Validation.py", "builtin:32"])
+    assert res.reason > 0 and res.its <= 6
     W4 = wh.reshape(-1, 4)
     near = lambda x, y, z: W4[np.argmin(((m.points - np.array([x, y, z])) ** 2).sum(axis=1)), 3]
     dp = near(0.45, 0.2, 0.205) - near(0.55, 0.2, 0.205)
     assert 6.15 < cd < 6.5 and abs(cl) < 0.05 and 0.15 < dp < 0.175, (cd, cl, dp)
-    P.close()
 
 
 def test_reynolds_continuation_rescues_a_failed_newton_solve(gpu):
@@ -987,6 +981,11 @@ def test_streamtrace_pipeline_from_the_output_files(gpu, tmp_path, monkeypatch):
     # the kept seeds are the ones whose backward trace ends inside the inner contour, near the inlet
     ended = rev["pos"][:, 0] < 0.5
     assert ended.sum() >= len(fo)
+    # ... and through the script's command line (streamtrace.py <img_fname> <solname> <funcname>, 50 x 50 seeds)
+    out2 = D.streamtrace_main(["streamtrace.py", str(tmp_path / "InletImages" / "asym.png"),
+                               str(folder / "Re5ChannelVelocity"), "Velocity"])
+    assert out2["rev_seeds"].shape == (2500, 3) and (tmp_path / "InletImages" / "final_output.csv").exists()
+    assert len(out2["final_output"]) > 100
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
