@@ -19,8 +19,9 @@ for f in glob.glob("gpurun_out/pmc_spmv/p*/**/*counter_collection.csv", recursiv
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "k_spmv<0, 1" in k: name = "fp64_ax"
-        elif "k_spmv_f32<2, 1" in k: name = "f32_jacobi_fine"
-        elif "k_spmv_f32<1, 1" in k: name = "f32_resid_fine"
+        elif "k_spmv_lp<2, 1" in k: name = "lp_jacobi_fine"
+        elif "k_spmv_lp<1, 1" in k: name = "lp_resid_fine"
+        elif "k_spmv_lp<2, 0" in k: name = "lp_jacobi_coarse"
         elif "k_fused_offdiag" in k: name = "fused_offdiag"
         else: continue
         e = d[(name, r["Counter_Name"])]
