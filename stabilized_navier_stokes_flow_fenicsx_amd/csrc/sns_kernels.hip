@@ -1521,8 +1521,9 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
         const int32_t cnt = e - s;
         const int32_t np = cnt >> 1;
         int32_t c[4];
+        const int32_t own = live ? row : 0;                       // dead lanes (row index past the end) gather block 0
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = (4 * t + r < cnt) ? colind[s + 4 * t + r] : row;
+        for (int t = 0; t < 4; ++t) c[t] = (4 * t + r < cnt) ? colind[s + 4 * t + r] : own;
         uint4 P[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
