@@ -60,6 +60,39 @@ class TetMesh:
 
 
 # --------------------------------------------------------------------------- #
+# triangle mesh -> one-cell-thick slab of tets (quasi-2-D problems on the 3-D path)
+# --------------------------------------------------------------------------- #
+def extrude_tri_mesh(points2d: np.ndarray, tris: np.ndarray, edges: np.ndarray, edge_tags: np.ndarray,
+                     thickness: float, *, zmin_tag: int = 6, zmax_tag: int = 7, tags: dict | None = None) -> TetMesh:
+    """Slab z in [0, thickness] over a conforming triangulation: every triangle becomes a prism cut into 3 tets.  The
+    vertical quad over an edge (a, b), a < b, is always cut along bottom-a -> top-b, so neighbouring prisms agree.
+    Nodes: bottom plane 0..N-1, top plane N..2N-1.  Boundary facets: the extruded boundary edges keep their 2-D tag,
+    the two z planes get ``zmin_tag`` / ``zmax_tag``.  With u_z = 0 imposed on both planes (every node lies on one)
+    the continuous 3-D problem is the 2-D one, which is how the 3-D forms are checked against 2-D reference values."""
+    p2 = np.asarray(points2d, dtype=np.float64)
+    N = len(p2)
+    pts = np.zeros((2 * N, 3))
+    pts[:N, :2] = p2
+    pts[N:, :2] = p2
+    pts[N:, 2] = thickness
+    t = np.sort(np.asarray(tris, dtype=np.int64), axis=1)              # v0 < v1 < v2
+    v0, v1, v2 = t[:, 0], t[:, 1], t[:, 2]
+    w0, w1, w2 = v0 + N, v1 + N, v2 + N
+    tets = np.concatenate([np.stack([v0, v1, v2, w2], axis=1), np.stack([v0, v1, w2, w1], axis=1),
+                           np.stack([v0, w0, w1, w2], axis=1)]).astype(np.int32)
+    e = np.sort(np.asarray(edges, dtype=np.int64), axis=1)             # a < b
+    a, b = e[:, 0], e[:, 1]
+    side = np.concatenate([np.stack([a, b, b + N], axis=1), np.stack([a, b + N, a + N], axis=1)])
+    side_tags = np.concatenate([edge_tags, edge_tags])
+    tr = np.asarray(tris, dtype=np.int64)
+    facets = np.concatenate([side, tr, tr + N]).astype(np.int32)
+    ftags = np.concatenate([side_tags, np.full(len(tr), zmin_tag), np.full(len(tr), zmax_tag)]).astype(np.int32)
+    meta = {"kind": "extruded", "thickness": float(thickness), "n2d": N,
+            "tags": dict(tags or {}, zmin=zmin_tag, zmax=zmax_tag)}
+    return TetMesh(pts, tets, facets, ftags, name="extruded", meta=meta)
+
+
+# --------------------------------------------------------------------------- #
 # structured box -> 6 Kuhn tets per cell
 # --------------------------------------------------------------------------- #
 _KUHN = []

@@ -360,6 +360,34 @@ def dfg2d_bcs(mesh: TriMesh, u_max: float = 0.3) -> DirichletSet:
     ])
 
 
+def dfg2d_slab_problem(n: float, u_max: float = 0.3):
+    """The DFG 2D-1 problem posed on the 3-D tet path: the built-in triangulation extruded to a one-cell slab
+    (``mesh.extrude_tri_mesh``, thickness = the mean triangle size) with u_z = 0 on both z planes -- every node lies on
+    one, so the 3-D problem is z-independent in the continuum (the prism split is not, which costs a 0.3 % difference
+    between the two planes on the coarse levels) and its drag / lift per unit depth must converge to the same constants (DFG_2D_Validation.py:202-203).  Inlet profile, no-slip sets and the natural outlet as ``dfg2d_bcs``.
+    Returns (TetMesh, (mask, g), thickness)."""
+    from . import mesh as M3
+    m2 = dfg_2d_mesh(n)
+    e = m2.points[m2.tris]
+    a, b = e[:, 1] - e[:, 0], e[:, 2] - e[:, 0]
+    thick = float(np.sqrt(np.abs(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]).mean()))
+    m3 = M3.extrude_tri_mesh(m2.points, m2.tris, m2.facets, m2.facet_tags, thick, tags=m2.meta["tags"])
+    t = m3.meta["tags"]
+    N = m3.num_nodes
+    mask = np.zeros(4 * N, np.uint8)
+    g = np.zeros(4 * N)
+    mask[2::4] = 1
+    H = 0.41
+    for name in ("walls", "obstacle", "inlet"):
+        nd = m3.facet_nodes(t[name])
+        for c in range(3):
+            mask[4 * nd + c] = 1
+        if name == "inlet":
+            y = m3.points[nd, 1]
+            g[4 * nd] = 4 * u_max * y * (H - y) / H ** 2
+    return m3, (mask, g), thick
+
+
 # ---- drag / lift (DFG_2D_Validation.py:195-200) ----------------------------------------------------------------
 DFG2D_CD_REF = 5.57953523384          # DFG_2D_Validation.py:203
 DFG2D_CL_REF = 0.010618948146         # DFG_2D_Validation.py:202

@@ -149,6 +149,47 @@ def test_dfg2d_series_converges_to_the_reference_constants():
     assert el[3] < 0.10 * M2.DFG2D_CL_REF and el[3] < el[0]
 
 
+def test_dfg2d_constants_on_the_3d_tet_path():
+    """The same pin for the 3-D kernels, i.e. for north_star's own path: DFG 2D-1 on a one-cell slab of tets
+    (mesh2d.dfg2d_slab_problem: u_z = 0 on both z planes, so the continuous 3-D problem is the 2-D one), the 3-D G-metric
+    SUPG/PSPG/LSIC forms of NavierStokesChannelFlow.py:220-251 AS WRITTEN (corrected_convection = 0) and with the
+    consistent (u.grad)u in the stabilisation terms (= 1), 3-D traction functional per unit depth.  Both must converge to
+    C_d = 5.57953523384 at first order (the functional takes the P1 gradient of the tet behind each facet) and they do so
+    from opposite sides -- measured, levels 2 / 4 / 8 / 12 / 16:  literal +0.705 / +0.324 / +0.205 / +0.108 / +0.054 %,
+    consistent -0.425 / -0.228 / -0.104 / -0.059 / -0.044 %.  C_l (0.2 % of the drag force) ends within 6 %."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import functionals as Fn
+    out = {0: [], 1: []}
+    for n in (2, 4, 8):
+        m3, (mask, g), thick = M2.dfg2d_slab_problem(n)
+        for corrected in (0, 1):
+            # residual entries scale with h^2 * thickness: the default snes_atol 1e-8 would stop after two digits
+            P = FlowProblem(m3, (mask, g), reynolds=1.0 / NU, corrected_convection=corrected, snes_atol=1e-15,
+                            snes_rtol=1e-11, snes_stol=1e-12, ksp_rtol=1e-10)
+            U, rs = P.stokes_solve()
+            assert rs.reason > 0
+            U.view(-1, 4)[:, 3] *= NU
+            w, rn = P.newton_solve(U.clone())
+            assert rn.reason > 0 and rn.fnorms[-1] < 1e-6 * rn.fnorms[0]
+            W = w.cpu().numpy()
+            assert np.all(W[2::4] == 0.0)
+            half = m3.num_nodes // 2       # bottom and top plane: the same 2-D field up to the asymmetry of the prism split
+            assert rel(W.reshape(-1, 4)[half:], W.reshape(-1, 4)[:half]) < 1e-2
+            F = Fn.boundary_traction_force(m3, W, NU, m3.meta["tags"]["obstacle"])
+            cd, cl = Fn.drag_lift_coefficients(F, Lc=0.1 * thick)
+            print(f"  DFG-2D on the 3-D path ({'consistent' if corrected else 'literal'}), level {n}: {m3.num_tets} tets, "
+                  f"C_d {cd:.6f} ({100 * (cd / M2.DFG2D_CD_REF - 1):+.3f} %), C_l {cl:.6f} "
+                  f"({100 * (cl / M2.DFG2D_CL_REF - 1):+.2f} %), Newton {rn.its} its, {rn.ksp_its} ksp its")
+            out[corrected].append((cd, cl))
+            P.close()
+    for corrected in (0, 1):
+        ed = [abs(cd - M2.DFG2D_CD_REF) for cd, _ in out[corrected]]
+        assert ed[1] < 0.6 * ed[0] and ed[2] < 0.7 * ed[1]
+        assert ed[2] < 0.0025 * M2.DFG2D_CD_REF
+        assert abs(out[corrected][2][1] - M2.DFG2D_CL_REF) < 0.06 * M2.DFG2D_CL_REF
+    for (cd0, _), (cd1, _) in zip(out[0], out[1]):
+        assert cd1 < M2.DFG2D_CD_REF < cd0                      # the two forms bracket the reference value on every level
+
+
 def test_lid_driven_cavity_2d_matches_oracle():
     """LidDrivenNavierStokesFlow.py <Re=100> <NumCells=24>: Stokes (nu, h^2/(12 nu)) then NS, vs the oracle."""
     Re, nc = 100.0, 24

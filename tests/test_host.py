@@ -544,3 +544,36 @@ def test_streamtrace_postprocessing_alpha_shape_blur_and_contour_filter():
     assert out.shape == (9, 2) and np.abs(out).max() <= 0.2 + 1e-12
     c = ST.update_contour(os.path.join(ROOT, "tests", "golden", "inlet_PlusF_final.png"))
     assert c.shape[1] == 3 and np.all(c[:, 0] == 0) and 5 < len(c) < 200 and np.abs(c[:, 1:]).max() < 0.5
+
+
+def test_extruded_slab_mesh_is_conforming_and_carries_the_2d_tags():
+    """mesh.extrude_tri_mesh / mesh2d.dfg2d_slab_problem: 3 tets per triangle filling the slab exactly, every interior face
+    shared by two tets, the boundary faces are exactly the listed facets (extruded boundary edges with their 2-D tags +
+    the two z planes), every node constrained in z, the inlet profile of DFG_2D_Validation.py:52."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import functionals as Fn, mesh2d as M2
+    m3, (mask, g), thick = M2.dfg2d_slab_problem(1)
+    m2 = M2.dfg_2d_mesh(1)
+    assert m3.num_nodes == 2 * m2.num_nodes and m3.num_tets == 3 * m2.num_cells
+    X = m3.points[m3.tets]
+    vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))) / 6
+    e = m2.points[m2.tris]
+    a, b = e[:, 1] - e[:, 0], e[:, 2] - e[:, 0]
+    area = 0.5 * np.abs(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
+    assert abs(vol.sum() - thick * area.sum()) < 1e-12 and vol.min() > 0.2 * thick * area.min() / 3
+    t = m3.tets.astype(np.int64)
+    faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+    u, c = np.unique(faces, axis=0, return_counts=True)
+    assert set(np.unique(c)) == {1, 2}
+    bnd = {tuple(f) for f in u[c == 1].tolist()}
+    assert len(bnd) == len(m3.facets) and all(tuple(sorted(f)) in bnd for f in m3.facets.tolist())
+    tg = m3.meta["tags"]
+    for name in ("inlet", "outlet", "walls", "obstacle"):
+        assert len(m3.find(tg[name])) == 2 * len(m2.find(tg[name]))
+    assert len(m3.find(tg["zmin"])) == m2.num_cells == len(m3.find(tg["zmax"]))
+    assert len(Fn.facet_parent_tets(m3, m3.find(tg["obstacle"]))) == 2 * len(m2.find(tg["obstacle"]))
+    assert mask[2::4].all() and not mask[3::4].any()
+    nd = m3.facet_nodes(tg["inlet"])
+    y = m3.points[nd, 1]
+    assert np.allclose(g[4 * nd], 4 * 0.3 * y * (0.41 - y) / 0.41 ** 2) and g[4 * nd].max() > 0.29
+    out_only = np.setdiff1d(m3.facet_nodes(tg["outlet"]), m3.facet_nodes(tg["walls"]))
+    assert not mask[4 * out_only].any() and not mask[4 * out_only + 1].any()       # natural outlet
