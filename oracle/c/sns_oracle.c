@@ -2,8 +2,8 @@
  * sns_oracle.c -- plain-C (OpenMP) CPU restatement of the reference's hot path.
  *
  * TEST INFRASTRUCTURE (see oracle/__init__.py): used only by tests/ and by
- * bench.py's cpu_baseline leg ("port").  PARITY UNPINNED: the reference ships no
- * fixtures for this path and cannot be executed here; this file restates
+ * bench.py's cpu_baseline leg ("port").  The reference ships no element-level
+ * fixtures and cannot be executed here (pins: oracle/__init__.py); this file restates
  *   - the element forms  NavierStokes/NavierStokesChannelFlow.py:160-172 (Stokes),
  *                        :220-251 (NS) and their exact derivative (:46)
  *   - the assembly + Dirichlet semantics of the .F/.J callbacks (:51-75)

@@ -1,7 +1,7 @@
 """Generate the committed golden vectors under tests/golden/ (run from the repo root).
 
 Test infrastructure (see oracle/__init__.py).  The reference cannot run here
-and ships no fixtures for this path (PARITY UNPINNED), so these vectors come
+and ships no element-level fixtures (its DFG-2D constants pin the converged functionals, oracle/__init__.py), so these vectors come
 from the oracle itself:
   element_ns.npz     residual/Jacobian of 12 tets from ``forms_literal`` (the
                      term-by-term UFL restatement + autograd), incl. the 4
