@@ -119,6 +119,13 @@ typedef struct {
                                a0/(4 nu), a0 = 1/3: LidDrivenNavierStokesFlow.py:98-100) */
     int    amg_fine_cycle;  /* shape of the AMG cycle on the fine level (single GPU): 0 = V(1,1) (default),
                                1 = V(0,1) (no pre-smoothing), 2 = V(1,0) (no post-smoothing) */
+    int    amg_nu_l1_pre;   /* sweeps BEFORE the coarse-grid correction on level 1 (0 = amg_nu_coarse, the default); the
+                               first one is omega D^-1 b from the zero guess, no matrix pass */
+    int    amg_nu_l1_post;  /* sweeps AFTER the coarse-grid correction on level 1 (0 = amg_nu_coarse, the default).
+                               Measured: 1 + 6 needs the iterations of 4 + 4 on the 10 M-tet duct at
+                               Re 200 with one level-1 matrix pass less per cycle (-3 % per Newton iteration), is neutral on
+                               the other workloads, costs 10 % more Stokes iterations and 8-11 % more iterations in
+                               partitioned runs (rank-local post-smoothing) -- hence off by default */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

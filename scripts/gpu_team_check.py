@@ -6,10 +6,11 @@ from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M, bcs as B, parti
 from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem, Team
 
 cells = eval(sys.argv[1]) if len(sys.argv) > 1 else (32, 8, 8)
+OPTS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("SNS_TEAM_OPTS", "").split(",") if kv)}
 Re = 200.0 * cells[1] / 75.0
 m = M.duct_mesh(cells, 4.0)
 mask, g = B.duct_bcs(m).flatten()
-Ps = FlowProblem(m, (mask, g), reynolds=Re)
+Ps = FlowProblem(m, (mask, g), reynolds=Re, **OPTS)
 Us, rs = Ps.stokes_solve()
 ws, ns = Ps.newton_solve(Us.clone())
 print("serial: stokes its", rs.its, "newton", ns.its, ns.reason, "ksp", ns.ksp_its, flush=True)
@@ -18,7 +19,7 @@ for nr in (2, 4, 8):
     team = Team(nr)
     def work(rank, team):
         part = PT.build_local_part(m, mask, g, owner, rank, nr)
-        P = FlowProblem(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team)
+        P = FlowProblem(part.mesh, (part.bc_mask, part.bc_val), reynolds=Re, part=part, group=team, **OPTS)
         U, r = P.stokes_solve()
         w, n = P.newton_solve(U.clone())
         res = (part, U.cpu().numpy(), r, w.cpu().numpy(), n, P.timings().amg_levels)

@@ -33,6 +33,8 @@ class SnsOptions(C.Structure):
         ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int), ("amg_f32_matrix", C.c_int), ("amg_nu_coarse", C.c_int), ("amg_nu_deep", C.c_int), ("amg_nu_l2", C.c_int), ("amg_sweep_exchange_rows", C.c_int), ("amg_replicate_rows", C.c_int), ("amg_post_exchange", C.c_int), ("assembly_fused", C.c_int),
         ("stokes_viscosity", C.c_double), ("stokes_beta", C.c_double),
         ("amg_fine_cycle", C.c_int),
+        ("amg_nu_l1_pre", C.c_int),
+        ("amg_nu_l1_post", C.c_int),
     ]
 
 

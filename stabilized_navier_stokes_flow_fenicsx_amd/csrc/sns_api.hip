@@ -1146,6 +1146,7 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     for (auto& L : h->levels) sig.push_back(L.omega);
     sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_nu_deep);
     sig.push_back(h->opt.amg_nu_l2);
+    sig.push_back(h->opt.amg_nu_l1_pre); sig.push_back(h->opt.amg_nu_l1_post);
     sig.push_back(h->opt.amg_f32_matrix);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
@@ -1251,7 +1252,16 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         return SNS_OK;
     }
     const int nu = level_nu(h, l);
-    const int nswaps = 2 * nu - 1;
+    // level 1: asymmetric sweep counts (amg_nu_l1_pre / amg_nu_l1_post; the first pre-sweep is omega D^-1 b)
+    int nu_pre = nu, nu_post = nu;
+    {
+        const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;
+        if (ll == 1) {
+            if (h->opt.amg_nu_l1_pre > 0) nu_pre = h->opt.amg_nu_l1_pre;
+            if (h->opt.amg_nu_l1_post > 0) nu_post = h->opt.amg_nu_l1_post;
+        }
+    }
+    const int nswaps = nu_pre - 1 + nu_post;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
     // distributed: on levels with few rows per rank the sweeps see the neighbours' current iterate (one small
@@ -1272,7 +1282,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         else
             hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
     }
-    for (int s = 1; s < nu; ++s) {
+    for (int s = 1; s < nu_pre; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
@@ -1310,7 +1320,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             HIP_TRY(hipMemcpyAsync(oth + 4 * (size_t)rows, cur + 4 * (size_t)rows, ghost4 * sizeof(double),
                                    hipMemcpyDeviceToDevice, h->stream));
     }
-    for (int s = s_first; s < nu; ++s) {
+    for (int s = s_first; s < nu_post; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
@@ -1797,6 +1807,8 @@ void sns_default_options(sns_options* o) {
     o->stokes_viscosity = 1.0;
     o->stokes_beta = 0.2;
     o->amg_fine_cycle = 0;
+    o->amg_nu_l1_pre = 0;
+    o->amg_nu_l1_post = 0;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }

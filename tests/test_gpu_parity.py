@@ -844,6 +844,29 @@ def test_low_precision_preconditioner_matrices_do_not_change_the_solution(gpu, k
         assert e > 0.0
 
 
+def test_asymmetric_level1_sweeps_option(gpu):
+    """amg_nu_l1_pre / amg_nu_l1_post (include/sns.h): 1 + 6 sweeps on level 1 instead of 4 + 4 -- another fixed linear
+    preconditioner: same converged fields, iteration counts within a few, and the options survive set_options."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    m = M.duct_mesh((40, 10, 10), 4.0)
+    mask, g = B.duct_bcs(m).flatten()
+    out = {}
+    for pre, post in ((0, 0), (1, 6), (2, 3)):
+        P = gpu(m, (mask, g), reynolds=50.0, ksp_rtol=1e-10, amg_coarse_size=16)
+        P.set_options(amg_nu_l1_pre=pre, amg_nu_l1_post=post)
+        assert (int(P.options.amg_nu_l1_pre), int(P.options.amg_nu_l1_post)) == (pre, post)
+        U, rs = P.stokes_solve()
+        w, rn = P.newton_solve(U.clone())
+        assert rs.reason > 0 and rn.reason > 0 and P.timings().amg_levels >= 3
+        out[(pre, post)] = (U.cpu().numpy(), w.cpu().numpy(), rs.its, rn.ksp_its)
+        P.close()
+    ref = out[(0, 0)]
+    for key in ((1, 6), (2, 3)):
+        assert rel(out[key][0], ref[0]) < 1e-7 and rel(out[key][1], ref[1]) < 1e-7
+        assert abs(out[key][2] - ref[2]) <= 8 and abs(out[key][3] - ref[3]) <= 25
+    assert out[(2, 3)][3] != ref[3] or out[(1, 6)][3] != ref[3]          # the options do change the cycle
+
+
 def _lib_rowptr(m):
     from stabilized_navier_stokes_flow_fenicsx_amd import _lib
     return _lib.host_pattern(m.num_nodes, m.tets)[0]
