@@ -383,6 +383,37 @@ def lid_driven_main(argv=None):
     return msh, wg, r
 
 
+def lid_driven_stokes_main(argv=None):
+    """LidDrivenStokesFlow.py (no arguments): Stokes flow in the 2-D unit square, 64 x 64 ``create_rectangle`` triangles
+    (:16-17), lid y = 1 moving with (1, 0), no slip on the other three sides (:20-56), nu = 0.01 and the pressure
+    stabilisation mu_T = a0 h^2 / (4 nu), a0 = 1/3 (:67-75), bcgs to 1e-10 (:81), norms of the coefficient vectors (:87-93),
+    XDMF + HDF5 output (:100-121).  The script's active element is Taylor-Hood P2-P1 with its P1-P1 line commented out
+    (:33-34); here it is the P1-P1 pair with exactly that stabilised form, as for DuctStokesFlow.py.
+    The script pins no pressure level; the hot path keeps the cavity's p = 0 at the origin of the NS script (the constant
+    is otherwise free)."""
+    from . import mesh2d as M2
+    argv = list(sys.argv if argv is None else argv)
+    n = int(argv[1]) if len(argv) > 1 else 64
+    nu = 0.01
+    msh = M2.rectangle_mesh(n)
+    print(f"There are this Many Degrees of Freedom in the Pressure Nodes: {msh.num_nodes}")
+    P = _problem(msh, M2.cavity2d_bcs(msh), reynolds=1.0 / nu, stokes_viscosity=nu, stokes_beta=(1.0 / 3.0) / (4.0 * nu),
+                 ksp_type="bicgstab", ksp_rtol=1e-10, ksp_atol=1e-10)
+    U, res = P.stokes_solve()
+    Ug = _to_global_host(P, U).reshape(-1, 4)
+    u, p = Ug[:, :2], Ug[:, 3]
+    if _rank() == 0:
+        print(f"\nL2 Norm of velocity coefficient vector: {np.linalg.norm(u)}")
+        print(f"Infinite Norm of velocity coefficient vector: {np.abs(u).max()}")
+        print(f"L2 Norm of pressure coefficient vector: {np.linalg.norm(p)}")
+        print(f"Infinite Norm of pressure coefficient vector: {np.abs(p).max()}")
+        print("\nFinished Solving, Saving Solution Field")
+        write_xdmf("StokesLidDrivenPressureHighRe", msh, "Pressure", p.copy())
+        write_xdmf("StokesLidDrivenVelocityHighRe", msh, "Velocity", u.copy())
+    P.close()
+    return msh, Ug.ravel(), res
+
+
 def dfg_2d_main(argv=None):
     """DFG_2D_Validation.py <msh file> (:22-28): Stokes with unit viscosity and mu_T = 0.2 h^2 (:101-125), NS with
     nu = 1e-3 and the UGN stabilisation from the Stokes field (:141-187), drag / lift and their relative errors
