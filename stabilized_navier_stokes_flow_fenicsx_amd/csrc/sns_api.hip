@@ -2390,7 +2390,7 @@ int sns_bench_spmv(sns_handle h, const double* x, double* y, int reps, double* m
 // interleaved A/B micro-benchmark of kernel variants on the assembled level-0 operator (methodology:
 // variants timed alternately in ONE process).  ms_out[v] = average launch ms of variant v.
 //   which 0: fp64 y = Ax, default loads (0) vs non-temporal matrix stream (1, production)
-//   which 3: fp64 y = Ax, production (0) vs the r1e loop (1)
+//   which 3: fp64 y = Ax, production (0: first 16 blocks up-front) vs the stepped loop of round 1 / early round 2 (1)
 //   which 1: low-precision Jacobi sweep, fp16 row-scaled (0) vs fp32 (1) (needs both copies: SNS_BOTH_LP=1)
 int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]) {
     if (!h || !ms_out || rounds <= 0 || reps <= 0) return SNS_E_ARG;
@@ -2409,7 +2409,7 @@ int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_
             for (int i = 0; i < reps; ++i) {
                 const int grid = (rows + 31) / 32;
                 if (which == 3) {
-                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                    if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 3, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                     else hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
                 } else if (which == 0) {
                     if (v) hipLaunchKernelGGL((k_spmv<SPMV_AX, 1, 1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.rowptr, L.colind, L.vals, x, y, nullptr, L.dinv, 0.0, nullptr, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
