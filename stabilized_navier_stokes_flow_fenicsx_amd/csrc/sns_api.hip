@@ -270,6 +270,15 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
                            b, L.dinv, omega, dotw, h->partial, h->bnd_rows, (const uint8_t*)nullptr, sp.partial_off);
     } else if (fine) {
         time_begin(h, MODE);
+        static const bool stepped = std::getenv("SNS_FP64_STEPPED") != nullptr;      // EXPERIMENT: in-solver A/B
+        if constexpr (MODE == SPMV_AX || MODE == SPMV_AX_DOT) {
+            if (stepped)
+                hipLaunchKernelGGL((k_spmv<MODE, 1, 3, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
+                                   x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+            else
+                hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
+                                   x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+        } else
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
                            x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
         time_end(h);
@@ -287,7 +296,15 @@ void launch_lp(sns_ctx* h, const Level& L, int32_t rows, hipStream_t st, const d
     const int grid = (rows + 63) / 64;
     if (grid == 0) return;
     const void* vals = FMT == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
-    hipLaunchKernelGGL((k_spmv_lp<MODE, FINE, SPLIT, FMT>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
+    static const bool lp_stepped = std::getenv("SNS_LP_STEPPED") != nullptr;       // EXPERIMENT: in-solver A/B
+    if constexpr (FMT == 2 && FINE == 1 && SPLIT == 0) {
+        if (lp_stepped) {
+            hipLaunchKernelGGL((k_spmv_lp<MODE, 1, 0, 2, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
+                               L.scale16, x, y, b, L.dinv32, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_spmv_lp<MODE, FINE, SPLIT, FMT, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
                        L.scale16, x, y, b, L.dinv32, omega, SPLIT == 2 ? h->bnd_rows : (const int32_t*)nullptr,
                        SPLIT == 1 ? h->bnd_flag : (const uint8_t*)nullptr);
 }

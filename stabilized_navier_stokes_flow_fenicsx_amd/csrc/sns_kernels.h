@@ -53,7 +53,7 @@ __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* col
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial, const int32_t* row_list, const uint8_t* skip,
                        int partial_off);
-template <int MODE, int FINE, int SPLIT, int FMT>
+template <int MODE, int FINE, int SPLIT, int FMT, int UP = 1>
 __global__ void k_spmv_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
                           const float* scale, const double* x, double* y, const double* bvec, const float* dinv32,
                           double omega, const int32_t* row_list, const uint8_t* skip);

@@ -1457,6 +1457,7 @@ SNS_INST_SPMV(SPMV_AX, 1, 1, 0)
 SNS_INST_SPMV(SPMV_AX, 1, 0, 0)
 SNS_INST_SPMV(SPMV_AX, 1, 2, 0)
 SNS_INST_SPMV(SPMV_AX, 1, 3, 0)
+SNS_INST_SPMV(SPMV_AX_DOT, 1, 3, 0)
 SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1, 0)
 SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 0)
 SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 0)
@@ -1511,7 +1512,7 @@ __device__ __forceinline__ double2 quad_bcast2(const double2 v) {
     return make_double2(quad_bcast<J>(v.x), quad_bcast<J>(v.y));
 }
 
-template <int MODE, int FINE, int SPLIT, int FMT>
+template <int MODE, int FINE, int SPLIT, int FMT, int UP>
 __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                                  const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
                                                  const float* __restrict__ scale, const double* __restrict__ x,
@@ -1544,7 +1545,7 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);       // FMT 1
     const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);         // FMT 2: pairs
     int32_t k = s;
-    if (FMT == 2) {
+    if (FMT == 2 && UP) {
         // The first 16 blocks of a row (all of it on a tet mesh's fine level: 15 blocks) are requested UP-FRONT: four
         // index loads, eight 16-B matrix loads, then the eight x loads -- three dependent round trips for the whole row
         // instead of two per step of 4 blocks.  The kernel is bound by the number of DRAM lines it keeps in flight
@@ -1643,21 +1644,22 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
                                                         (double)pre_d.w * r3);
     }
 }
-#define SNS_INST_LP(M, F, S, T)                                                                                    \
-    template __global__ void k_spmv_lp<M, F, S, T>(int32_t, const int32_t*, const int32_t*, const void*,              \
-                                                   const float*, const double*, double*, const double*,              \
-                                                   const float*, double, const int32_t*, const uint8_t*);
-#define SNS_INST_LP_FMT(T)                \
-    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, T) \
-    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 1, T) \
-    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 2, T) \
-    SNS_INST_LP(SPMV_B_MINUS_AX, 0, 0, T) \
-    SNS_INST_LP(SPMV_JACOBI, 1, 0, T)     \
-    SNS_INST_LP(SPMV_JACOBI, 1, 1, T)     \
-    SNS_INST_LP(SPMV_JACOBI, 1, 2, T)     \
-    SNS_INST_LP(SPMV_JACOBI, 0, 0, T)
+#define SNS_INST_LP(M, F, S, T, U)                                                                                 \
+    template __global__ void k_spmv_lp<M, F, S, T, U>(int32_t, const int32_t*, const int32_t*, const void*,           \
+                                                      const float*, const double*, double*, const double*,           \
+                                                      const float*, double, const int32_t*, const uint8_t*);
+#define SNS_INST_LP_FMT(T)                   \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, T, 1) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 1, T, 1) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 2, T, 1) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 0, 0, T, 1) \
+    SNS_INST_LP(SPMV_JACOBI, 1, 0, T, 1)     \
+    SNS_INST_LP(SPMV_JACOBI, 1, 1, T, 1)     \
+    SNS_INST_LP(SPMV_JACOBI, 1, 2, T, 1)     \
+    SNS_INST_LP(SPMV_JACOBI, 0, 0, T, 1)
 SNS_INST_LP_FMT(1)
 SNS_INST_LP_FMT(2)
+SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, 2, 0) SNS_INST_LP(SPMV_JACOBI, 1, 0, 2, 0)      // in-solver A/B of the stepped loop
 
 // fp16 copy of a BSR4 matrix with one scale per dof row, in the pair-interleaved layout k_spmv_lp<FMT 2> reads:
 // 4 lanes per block row, lane r owns dof row 4*row + r.  Block j of a row (j = k - rowptr[row]) that has a partner
