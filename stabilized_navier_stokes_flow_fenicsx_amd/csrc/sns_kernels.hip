@@ -1545,21 +1545,23 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);       // FMT 1
     const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);         // FMT 2: pairs
     int32_t k = s;
-    if (FMT == 2 && UP) {
-        // The first 16 blocks of a row (all of it on a tet mesh's fine level: 15 blocks) are requested UP-FRONT: four
-        // index loads, eight 16-B matrix loads, then the eight x loads -- three dependent round trips for the whole row
-        // instead of two per step of 4 blocks.  The kernel is bound by the number of DRAM lines it keeps in flight
-        // (PMC: 20 k lines against 40 k for the fp64 kernel), not by bytes, issue or ALU work.
-        // Missing blocks are masked: zero matrix values, the row's own (valid) x block.
+    if constexpr (FMT == 2 && UP > 0) {
+        // The first 16 * UP blocks of a row (UP = 1: all of it on a tet mesh's fine level, 15 blocks) are requested UP-FRONT:
+        // the index loads, the 16-B matrix loads, then the x loads -- three dependent round trips for the whole row instead
+        // of two per step of 4 blocks.  (UP = 2, 32 blocks for the 27-block rows of the coarse levels, was measured in the
+        // solver and is slower: 168 VGPRs, level-1 sweep 40 instead of 36 us.)  The kernel
+        // is latency-sensitive (PMC: 20 k DRAM lines in flight against 40 k for the fp64 kernel),
+        // not bound by bytes, issue or ALU work.  Missing blocks are masked: zero matrix values, the row's own x block.
+        constexpr int NS = 4 * UP;                                // steps of 4 blocks requested up-front
         const int32_t cnt = e - s;
         const int32_t np = cnt >> 1;
-        int32_t c[4];
+        int32_t c[NS];
         const int32_t own = live ? row : 0;                       // dead lanes (row index past the end) gather block 0
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = (4 * t + r < cnt) ? colind[s + 4 * t + r] : own;
-        uint4 P[8];
+        for (int t = 0; t < NS; ++t) c[t] = (4 * t + r < cnt) ? colind[s + 4 * t + r] : own;
+        uint4 P[2 * NS];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 2 * NS; ++q) {
             P[q] = make_uint4(0u, 0u, 0u, 0u);
             if (q < np) P[q] = v16[4 * q];
             else if (q == np && (cnt & 1)) {                      // the odd last block (plain layout) as the low half of a pair
@@ -1567,22 +1569,22 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
                 P[q].x = o.x; P[q].y = o.y;
             }
         }
-        double2 xa[4], xb[4];
+        double2 xa[NS], xb[NS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NS; ++t) {
             const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)c[t]);
             xa[t] = xp[0]; xb[t] = xp[1];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NS; ++t) {
             const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&P[2 * t]), h1 = *reinterpret_cast<const f16x8_t*>(&P[2 * t + 1]);
             acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa[t]), quad_bcast2<0>(xb[t]));
             acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa[t]), quad_bcast2<1>(xb[t]));
             acc0 += lp_dot(h1.lo, quad_bcast2<2>(xa[t]), quad_bcast2<2>(xb[t]));
             acc1 += lp_dot(h1.hi, quad_bcast2<3>(xa[t]), quad_bcast2<3>(xb[t]));
         }
-        k = (cnt > 16) ? s + 16 : e;                              // longer rows (coarse levels, unstructured meshes): the loop below
-        v16 += 32;
+        k = (cnt > 4 * NS) ? s + 4 * NS : e;                      // longer rows (unstructured meshes): the loop below
+        v16 += 8 * NS;
     }
     // the block ids of the NEXT step are requested one step ahead: index -> x gather is a dependent chain of two
     // memory round trips per step otherwise (matters on the coarse levels, whose rows have ~27 blocks = 7 steps)
