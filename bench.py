@@ -256,7 +256,7 @@ def main():
     #   per block row:     4 rowptr + 32 per vector touched (x, b, y, dot weight) + D^-1 (Jacobi: 128 B fp64, 64 B as the
     #                      fp32 copy the low-precision sweeps read) + 16 row scales (fp16)
     fmt = int(P.options.amg_f32_matrix)
-    lp = {0: ("k_spmv<{m}, 1, 1, 0>", 132.0, 0.0), 1: ("k_spmv_lp<{m}, 1, 0, 1>", 68.0, 0.0), 2: ("k_spmv_lp<{m}, 1, 0, 2>", 36.0, 16.0)}[fmt]
+    lp = {0: ("k_spmv<{m}, 1, 1, 0>", 132.0, 0.0), 1: ("k_spmv_lp<{m}, 1, 0, 1, 1>", 68.0, 0.0), 2: ("k_spmv_lp<{m}, 1, 0, 2, 1>", 36.0, 16.0)}[fmt]
     nb, nr = float(s["nnzb"]), float(s["n_owned"])
     kinfo = {
         "jacobi": (lp[0].format(m=2), lp[1] * nb + (4 + 32 * 3 + (128 if fmt == 0 else 64) + lp[2]) * nr,
@@ -274,7 +274,9 @@ def main():
             per_kernel[key] = {"kernel": kname_k, "what": what, "avg_launch_ms": round(avg, 5), "launches": int(calls_k),
                                "total_ms": round(ms_k, 2), "algorithmic_bytes_per_launch": bytes_k,
                                "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(kname_k) if cfg == 5 else None}
+                               # (profiles older than r2e carry the low-precision kernel without its last template argument)
+                               "traffic": pmc_traffic(kname_k[:kname_k.rindex(",")] if kname_k.startswith("k_spmv_lp") else kname_k)
+                               if cfg == 5 else None}
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k_: per_kernel[k_]["total_ms"])       # dominant = largest total time, live

@@ -333,7 +333,7 @@ def test_bench_helpers_without_gpu():
     assert after == before                                   # cpu_baseline imports the oracle lazily, only when it runs
     t = bench.pmc_traffic("k_spmv_f32<2, 1")
     assert t is not None and 2.0e9 < t < 3.0e9               # 2.14 GB algorithmic, ~2.4 GB measured
-    t2 = bench.pmc_traffic("k_spmv_lp<2, 1, 0, 2>")          # round 2: fp16 Jacobi sweep, 1.24 GB algorithmic
+    t2 = bench.pmc_traffic("k_spmv_lp<2, 1, 0, 2")          # round 2: fp16 Jacobi sweep, 1.24 GB algorithmic
     assert t2 is not None and 1.2e9 < t2 < 1.8e9
     t3 = bench.pmc_traffic("k_spmv<0, 1, 1, 0>")             # fp64 Krylov operator: 3.51 GB algorithmic
     assert t3 is not None and 3.4e9 < t3 < 3.7e9
