@@ -4,25 +4,149 @@ on the 10.1 M-tet square duct (BASELINE.json configs[4], the configuration the m
 is quoted on; it fits one MI355X), Re = 200.
 
 A "step" is ONE Newton iteration of a real Newton sequence started from the Stokes
-solution: fused Jacobian+residual assembly (HIP), AMG setup, FGMRES solve to rtol 1e-8
+solution: fused Jacobian+residual assembly (HIP), AMG setup, BiCGStab solve to rtol 1e-8
 (the reference's KSP tolerance, NavierStokesChannelFlow.py:283), bt line-search residual.
 When the sequence converges (||F|| < 1e-8, :281) it restarts from the Stokes solution.
 metric = M-DOF/s = N_dof / (t_assemble + t_solve) per Newton iteration / 1e6  (SURVEY 8d).
 
-  python bench.py [--gpus N --steps K --warmup W]           (N>1 under torch.distributed.run)
-N>1: the HEADLINE is what north_star states -- the SAME 10.1 M-tet duct element-partitioned into N x-slabs (strong
+  python bench.py [--gpus N --steps K --warmup W]
+N>1: `python bench.py --gpus N` started as a plain command launches its own N ranks (one per GPU, torch.distributed.run
+on 127.0.0.1), relays rank 0's JSON line and exits with the workers' return code; started under an external
+torch.distributed.run (the driver's way) it runs as the rank it is given.  WORLD_SIZE != --gpus is an error.
+The HEADLINE is what north_star states -- the SAME 10.1 M-tet duct element-partitioned into N x-slabs (strong
 scaling; every rank meshes only its own slab), halo exchange and dot-product all-reduces on RCCL inside libsns.so.
 The weak layout (duct refined by N^(1/3) per direction, every GPU keeps a ~10.1 M-tet slab) is timed afterwards and
 reported under "weak_scaling" in the same JSON line (--no-weak skips it).
---config 3 / 4 time the other full-size BASELINE configs (55^3 cavity Re 100; 240x60x60 two-stream channel) as
-secondary lines; the default (5) is the headline.
+--config 3 / 4 / 4u time the other full-size BASELINE configs as secondary lines; the default (5) is the headline.
+--dry-run: the launch + partition + halo-plan + collective path WITHOUT any HIP call (gloo on the CPU): what the
+CPU test-suite runs with --gpus 2.
+Environment: SNS_NO_OVERLAP=1 = exchange-then-full-pass instead of the overlapped interior/boundary split (the
+fallback if the overlapped RCCL path misbehaves on a new machine); SNS_WATCHDOG_S = seconds without progress after
+which a rank exits non-zero (default 900; 0 = off).
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=str, default="5", choices=["3", "4", "4u", "5"],
+                    help="BASELINE config: 5 = 10.1 M-tet duct Re 200 (headline), 3 = 55^3 cavity Re 100, "
+                         "4 = 240x60x60 channel Re 50 with the inlet profiles of the reference's Plus image "
+                         "(--inlet analytic: the two-stream substitute of round 2), 4u = Delaunay channel (~5 M tets)")
+    ap.add_argument("--inlet", type=str, default="image", choices=["image", "analytic"],
+                    help="config 4: inlet data from tests/golden/inlet_PlusF_final.png (default) or analytic")
+    ap.add_argument("--cells", type=str, default=None)
+    ap.add_argument("--length", type=float, default=4.0, help="duct length")
+    ap.add_argument("--re", type=float, default=None)
+    ap.add_argument("--ksp", type=str, default="bicgstab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-maxit", type=int, default=200, help="iteration bound of the CPU baseline's Krylov solve")
+    ap.add_argument("--no-f64-rerun", action="store_true", help="skip the all-fp64 repetition of the timed steps")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaling layout after the headline")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
+    ap.add_argument("--strong", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no HIP: launch, partition, halo plans and one all-reduce on gloo (CPU rehearsal of --gpus N)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="self-launched runs: kill the workers and exit non-zero after this many seconds")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` as a plain command: start N workers (one per GPU) BEFORE anything touches the GPU
+    or imports torch in this process, relay their output, return their exit code.  Never exec()s."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    killed = []
+
+    def reaper():
+        if proc.poll() is None:
+            killed.append(True)
+            print(f"[bench] launch timeout after {args.launch_timeout:.0f} s: killing the workers", file=sys.stderr, flush=True)
+            try:
+                os.killpg(proc.pid, 9)                 # the session we created: our workers and nothing else
+            except OSError:
+                proc.kill()
+
+    timer = threading.Timer(args.launch_timeout, reaper)
+    timer.daemon = True
+    timer.start()
+    got_json = False
+    for line in proc.stdout:                           # rank 0's JSON line (and anything else the workers print)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            got_json = True
+    rc = proc.wait()
+    timer.cancel()
+    if killed:
+        return 124
+    if rc == 0 and not got_json:
+        print("[bench] workers exited 0 without a result line", file=sys.stderr, flush=True)
+        return 3
+    return rc
+
+
+class Watchdog:
+    """A rank that makes no progress for SNS_WATCHDOG_S seconds exits non-zero (os._exit: no re-exec, no clean-up
+    that could hang on a stuck collective); torch.distributed.run then tears the other ranks down."""
+
+    def __init__(self, rank):
+        self.limit = float(os.environ.get("SNS_WATCHDOG_S", "900"))
+        self.rank = rank
+        self.last = time.monotonic()
+        self.what = "start"
+        if self.limit > 0:
+            t = threading.Thread(target=self._run, daemon=True)
+            t.start()
+
+    def tick(self, what):
+        self.last = time.monotonic()
+        self.what = what
+
+    def _run(self):
+        while True:
+            time.sleep(min(5.0, max(0.05, self.limit / 4)))
+            if time.monotonic() - self.last > self.limit:
+                print(f"[bench] watchdog: rank {self.rank} made no progress for {self.limit:.0f} s after '{self.what}': "
+                      "exiting 86", file=sys.stderr, flush=True)
+                os._exit(86)
+
+
+WATCHDOG = None
+
+if __name__ == "__main__":
+    _ARGS = parse_args()
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != max(1, _ARGS.gpus):
+        print(f"error: --gpus {_ARGS.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} (start `python bench.py --gpus N` as a "
+              "plain command, or run it under torch.distributed.run with --nproc-per-node N)", file=sys.stderr)
+        sys.exit(2)
+    if _ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(_ARGS, sys.argv[1:]))
 
 # the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this before HIP initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -76,12 +200,13 @@ def cpu_baseline(mesh, mask, g, U, Re, maxit=200):
 
 
 def pmc_traffic(kernel_substr):
-    """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc CSVs
-    (profiles/*pmc*counter_collection.csv), corrected as MI355X_MICROARCH.md prescribes:
-    FETCH_SIZE is in KiB and reads half the bytes of a wide streaming read on gfx950 (x2);
-    WRITE_SIZE (KiB) is exact.  None if no such profile is committed."""
+    """(bytes, source file names): per-launch HBM bytes of a kernel from the COMMITTED rocprofv3 --pmc CSVs
+    (profiles/*pmc*counter_collection.csv; not measured in this run -- `traffic_source` in the line names the files),
+    corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and reads half the bytes of a wide streaming
+    read on gfx950 (x2); WRITE_SIZE (KiB) is exact.  (None, None) if no such profile is committed."""
     import csv
     fetch = write = None
+    src = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*counter_collection.csv"))):   # latest round wins
         tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
         with open(f) as fh:
@@ -91,45 +216,112 @@ def pmc_traffic(kernel_substr):
                     tot[row["Counter_Name"]][1] += 1
         if tot["FETCH_SIZE"][1]:
             fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] * 1024.0 * 2.0
+            src["fetch"] = os.path.basename(f)
         if tot["WRITE_SIZE"][1]:
             write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] * 1024.0
+            src["write"] = os.path.basename(f)
     if fetch is None or write is None:
-        return None
-    return fetch + write
+        return None, None
+    return fetch + write, f"profiles/{src['fetch']} + profiles/{src['write']} (committed PMC passes, not this run)"
 
-def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on):
+
+def host_problem(cfg, cells, length, inlet="image"):
+    """(mesh, (mask, g), description) of configs 3 / 4 / 4u on the host (setup, not timed)."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    if cfg == "3":                         # LidDrivenNavierStokesFlow.py extended to the unit cube (SURVEY 8, config 3)
+        mesh = M.cavity_mesh(cells[0])
+        return mesh, B.cavity_bcs(mesh).flatten(), f"lid-driven unit cube, {cells[0]}^3 cells"
+    if cfg == "4u":                        # the reference's production meshes are gmsh Delaunay (image2gmsh3D.py:445-486)
+        mesh = M.delaunay_channel_mesh(cells[0], lattice="bcc")
+        return (mesh, B.channel_bcs(mesh, *B.two_stream_profiles(0.5)).flatten(),
+                f"two-stream channel 4x1x1 on an UNSTRUCTURED Delaunay mesh (body-centred lattice, h = 1/{cells[0]}), "
+                "flowrate ratio 0.5")
+    if inlet == "image":                   # NavierStokesChannelFlow.py:102-117,150-157 on the reference's own input image
+        from stabilized_navier_stokes_flow_fenicsx_amd import inlet_image as II
+        img = os.path.join(ROOT, "tests", "golden", "inlet_PlusF_final.png")
+        mesh, bcs, _ = II.channel_from_image(img, 0.5, cells)
+        return mesh, bcs, (f"channel 4x1x1, {cells[0]}x{cells[1]}x{cells[2]} cells, inlet profiles + nozzle walls from the "
+                           "reference's Plus image (InletImages/PlusF_final.png, box-filtered copy), flowrate ratio 0.5")
+    mesh = M.channel_mesh(cells)
+    return (mesh, B.channel_bcs(mesh, *B.two_stream_profiles(0.5)).flatten(),
+            f"two-stream channel 4x1x1, {cells[0]}x{cells[1]}x{cells[2]} cells, analytic inlet profiles, flowrate ratio 0.5")
+
+
+def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on, inlet="image"):
     """(P, n_dof_global, n_tets_global, description, host_inputs) of one BASELINE config on this rank.
     Config 5 (duct): x-slab element partition, every rank meshes only its own slab (partition.duct_slab_part).
-    Configs 3 / 4: the global mesh is built on every rank and RCB-partitioned (setup cost, not timed)."""
+    Configs 3 / 4 / 4u: the global mesh is built on every rank and RCB-partitioned (setup cost, not timed)."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
     from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem
     dev = f"cuda:{local_rank}"
     host = None
-    if cfg == 5:
+    if cfg == "5":
         if dist_on:
             part = PT.duct_slab_part(cells, length, rank, world)
             P = FlowProblem.from_part(part, device=dev, **opts)
         else:
             mesh = M.duct_mesh(cells, length)
-            bcs = B.duct_bcs(mesh)
+            bcs = B.duct_bcs(mesh).flatten()
             P = FlowProblem(mesh, bcs, device=dev, **opts)
             host = (mesh, bcs)
         nd = 4 * (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
         nt = 6 * cells[0] * cells[1] * cells[2]
         desc = f"duct [0,{length:g}]x[-.5,.5]^2, {cells[0]}x{cells[1]}x{cells[2]} cells"
     else:
-        if cfg == 3:                       # LidDrivenNavierStokesFlow.py extended to the unit cube (SURVEY 8, config 3)
-            mesh = M.cavity_mesh(cells[0])
-            bcs = B.cavity_bcs(mesh)
-            desc = f"lid-driven unit cube, {cells[0]}^3 cells"
-        else:                              # NavierStokesChannelFlow.py two-stream inlet, ratio 0.5 (config 4)
-            mesh = M.channel_mesh(cells)
-            bcs = B.channel_bcs(mesh, *B.two_stream_profiles(0.5))
-            desc = f"two-stream channel 4x1x1, {cells[0]}x{cells[1]}x{cells[2]} cells, flowrate ratio 0.5"
+        mesh, bcs, desc = host_problem(cfg, cells, length, inlet)
         P = FlowProblem.distributed(mesh, bcs, device=dev, **opts) if dist_on else FlowProblem(mesh, bcs, device=dev, **opts)
         host = (mesh, bcs)
         nd, nt = mesh.num_dofs, mesh.num_tets
     return P, nd, nt, desc, host
+
+
+def dry_run(args, cfg, cells, length, world, rank):
+    """--dry-run: everything `--gpus N` does up to the first HIP call, on the CPU: rendezvous (gloo), this rank's
+    partition, the halo plan checked against the neighbours' (one real exchange of node ids), the boundary-row split
+    libsns.so derives from it, and one all-reduce.  Prints the same kind of JSON line (value null)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib, partition as PT
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    WATCHDOG.tick("rendezvous")
+    if cfg == "5":
+        part = PT.duct_slab_part(cells, length, rank, world)
+        nt = 6 * cells[0] * cells[1] * cells[2]
+    else:
+        mesh, (mask, g), _ = host_problem(cfg, cells, length, args.inlet)
+        part = PT.build_local_part(mesh, mask, g, PT.rcb_partition(mesh.points, world), rank, world)
+        nt = mesh.num_tets
+    WATCHDOG.tick("partition")
+    # halo plan: send the GLOBAL ids of the nodes I send; what arrives must be the global ids of my ghost slots
+    gid = torch.from_numpy(np.repeat(part.l2g.astype(np.float64), 4))
+    gid[4 * part.n_owned:] = -1.0
+    if world > 1:
+        PT.halo_exchange_torch(part, gid)
+    halo_ok = bool(np.array_equal(gid.numpy()[::4].astype(np.int64), part.l2g))
+    rp, ci, _, _ = _lib.host_pattern(part.n_local, part.mesh.tets)
+    bnd = _lib.host_boundary_rows(part.n_owned, rp, ci)
+    t = torch.tensor([float(part.n_owned), float(len(bnd)), 1.0 if halo_ok else 0.0, float(len(part.send_idx))],
+                     dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    WATCHDOG.tick("collectives")
+    if os.environ.get("SNS_DRYRUN_STALL_RANK") == str(rank):      # test hook: a rank that never comes back
+        time.sleep(3600)
+    out = {"metric": "M-DOF/s (assembly+solve) per Newton iteration", "value": None, "unit": "M-DOF/s", "n_gpus": world,
+           "dry_run": True, "transport": "gloo (CPU rehearsal, no HIP)", "rccl_ranks": None, "steps": 0, "warmup": 0,
+           "config": {"workload": f"BASELINE config {cfg}: {nt} tets, partition + halo plans + one all-reduce only",
+                      "parallelism": f"element partition x{world}", "owned_nodes_total": int(t[0]),
+                      "boundary_rows_total": int(t[1]), "halo_plans_consistent_ranks": int(t[2]),
+                      "halo_send_nodes_total": int(t[3]), "neighbours_of_rank0": [int(x) for x in part.neighbors]}}
+    ok = int(t[2]) == world
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 4
 
 
 def timed_newton_steps(P, U, steps, warmup, world):
@@ -158,6 +350,8 @@ def timed_newton_steps(P, U, steps, warmup, world):
 
     for _ in range(warmup):
         step()
+        if WATCHDOG:
+            WATCHDOG.tick("warm-up step")
     P.reset_timings()
     P.time_kernels(True)
     log.clear()
@@ -165,6 +359,8 @@ def timed_newton_steps(P, U, steps, warmup, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+        if WATCHDOG:
+            WATCHDOG.tick("timed step")                # a time stamp only: nothing inside the timed region waits on it
     barrier()
     dt = time.perf_counter() - t0
     P.time_kernels(False)
@@ -176,25 +372,8 @@ def timed_newton_steps(P, U, steps, warmup, world):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=5, choices=[3, 4, 5],
-                    help="BASELINE config: 5 = 10.1 M-tet duct Re 200 (headline), 3 = 55^3 cavity Re 100, "
-                         "4 = 240x60x60 two-stream channel Re 50")
-    ap.add_argument("--cells", type=str, default=None)
-    ap.add_argument("--length", type=float, default=4.0, help="duct length")
-    ap.add_argument("--re", type=float, default=None)
-    ap.add_argument("--ksp", type=str, default="bicgstab")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-maxit", type=int, default=200, help="iteration bound of the CPU baseline's Krylov solve")
-    ap.add_argument("--no-f64-rerun", action="store_true", help="skip the all-fp64 repetition of the timed steps")
-    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaling layout after the headline")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
-    ap.add_argument("--strong", action="store_true", help="(default since round 2; kept for old command lines)")
-    args = ap.parse_args()
+    global WATCHDOG
+    args = parse_args()
 
     import torch
     import torch.distributed as dist
@@ -202,8 +381,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != max(1, args.gpus):                              # (also checked before torch was imported)
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        return 2
+    WATCHDOG = Watchdog(rank)
+    cfg = args.config
+    default_cells = {"5": "300,75,75", "4": "240,60,60", "4u": "47", "3": "55,55,55"}[cfg]
+    cells = tuple(int(c) for c in (args.cells or default_cells).split(","))
+    length = args.length
+    if args.dry_run:
+        return dry_run(args, cfg, cells, length, world, rank)
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get("SNS_FORCE_DIST"))          # rehearse the partitioned path with one rank
     dist_on = world > 1 or force_dist
@@ -214,21 +401,24 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    cfg = args.config
-    default_cells = {5: "300,75,75", 4: "240,60,60", 3: "55,55,55"}[cfg]
-    cells = tuple(int(c) for c in (args.cells or default_cells).split(","))
-    Re = args.re if args.re is not None else {5: 200.0, 4: 50.0, 3: 100.0}[cfg]
+    Re = args.re if args.re is not None else {"5": 200.0, "4": 50.0, "4u": 50.0, "3": 100.0}[cfg]
     opts = dict(reynolds=Re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
     for kv in args.opt:
         k, v = kv.split("=", 1)
         opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
-    length = args.length
 
     # ---- headline: the SAME mesh on N GPUs (strong scaling; N = 1 is the mesh on one GPU) ----------------------
-    P, n_dof_global, n_tets_global, desc, host = build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on)
+    P, n_dof_global, n_tets_global, desc, host = build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on,
+                                                               args.inlet)
+    WATCHDOG.tick("setup")
+    comm = P.comm_info()
+    if dist_on and world > 1 and comm["rccl_ranks"] != world:
+        print(f"error: RCCL communicator has {comm['rccl_ranks']} ranks, expected {world}", file=sys.stderr)
+        return 5
     U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
     if sres.reason <= 0:
         raise RuntimeError(f"Stokes solve did not converge: {sres}")
+    WATCHDOG.tick("stokes")
     ms_per_step, log, w = timed_newton_steps(P, U, args.steps, args.warmup, world)
     value = n_dof_global / (ms_per_step * 1e-3) / 1e6
 
@@ -275,8 +465,10 @@ def main():
                                "total_ms": round(ms_k, 2), "algorithmic_bytes_per_launch": bytes_k,
                                "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                                # (profiles older than r2e carry the low-precision kernel without its last template argument)
-                               "traffic": pmc_traffic(kname_k[:kname_k.rindex(",")] if kname_k.startswith("k_spmv_lp") else kname_k)
-                               if cfg == 5 else None}
+                               "traffic": None, "traffic_source": None}
+            if cfg == "5":
+                per_kernel[key]["traffic"], per_kernel[key]["traffic_source"] = pmc_traffic(
+                    kname_k[:kname_k.rindex(",")] if kname_k.startswith("k_spmv_lp") else kname_k)
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k_: per_kernel[k_]["total_ms"])       # dominant = largest total time, live
@@ -284,7 +476,7 @@ def main():
         fam_bytes = sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in per_kernel.values())
         fam_ms = sum(v["total_ms"] for v in per_kernel.values())
         roofline = {"bound": "hbm", "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
-                    "traffic": d["traffic"], "kernel": d["kernel"], "what": d["what"],
+                    "traffic": d["traffic"], "traffic_source": d["traffic_source"], "kernel": d["kernel"], "what": d["what"],
                     "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
                     "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                     "selection": "the fine-level SpMV kernel with the largest total time inside the timed region "
@@ -311,7 +503,8 @@ def main():
                                                          if P.options.assembly_fused else None)}}
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
-        "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "rccl_ranks": comm["rccl_ranks"],
+        "transport": comm["transport"], "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "precision_note": ("operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "
@@ -343,11 +536,12 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- second key for N > 1: the weak layout (every GPU keeps the single-GPU share) --------------------------
-    if cfg == 5 and dist_on and not args.no_weak:
+    WATCHDOG.tick("headline done")
+    if cfg == "5" and dist_on and not args.no_weak:
         sc = float(world) ** (1.0 / 3.0)
         wcells = tuple(int(round(c * sc)) for c in cells)
         try:                                  # a failure of the second key must not cost the headline line
-            Pw, nd_w, nt_w, desc_w, _ = build_problem(5, wcells, length, Re, world, rank, local_rank, opts, True)
+            Pw, nd_w, nt_w, desc_w, _ = build_problem("5", wcells, length, Re, world, rank, local_rank, opts, True)
             Uw, sw = Pw.stokes_solve()
             if sw.reason > 0:
                 ms_w, log_w, _ = timed_newton_steps(Pw, Uw, args.steps, args.warmup, world)
@@ -363,13 +557,15 @@ def main():
 
     if rank == 0:
         if U_host is not None and not args.no_cpu_baseline:
-            mesh, bcs = host
-            mask, g = bcs.flatten()
+            mesh, (mask, g) = host
+            WATCHDOG.limit = 0 if WATCHDOG.limit <= 0 else max(WATCHDOG.limit, 3600.0)      # a long host-only leg
+            WATCHDOG.tick("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(mesh, mask, g, U_host, Re, maxit=args.cpu_maxit)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -126,6 +126,9 @@ typedef struct {
                                Re 200 with one level-1 matrix pass less per cycle (-3 % per Newton iteration), is neutral on
                                the other workloads, costs 10 % more Stokes iterations and 8-11 % more iterations in
                                partitioned runs (rank-local post-smoothing) -- hence off by default */
+    int    amg_retry_damping; /* 1 (default): a Krylov solve that ends in BREAKDOWN or NANORINF under SNS_PC_AMG is retried
+                               once from the same guess with every level's block-Jacobi damping scaled by 0.7 (see
+                               sns_krylov_solve); 0: the failed reason is reported and that is it, as PETSc does */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
@@ -205,10 +208,13 @@ int sns_spmv(sns_handle h, const double* x_dev, double* y_dev);
 int sns_pc_setup(sns_handle h);
 int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
 /* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
- * guess on entry.  rnorm = final true-residual 2-norm.  A solve that FAILS under
- * SNS_PC_AMG is retried once from the same guess with every level's block-Jacobi
- * damping scaled by 0.7 (kept for later solves of the handle); *its counts both
- * attempts, *reason is the last attempt's.                                     */
+ * guess on entry.  rnorm = 2-norm of the TRUE residual b - A x at exit.  With
+ * amg_retry_damping (default on) a solve that ends in DIVERGED_BREAKDOWN or
+ * DIVERGED_NANORINF under SNS_PC_AMG is retried ONCE from the same guess with every
+ * level's block-Jacobi damping scaled by 0.7; the factor stays until the next
+ * sns_set_options.  *its then counts both attempts (<= 2 ksp_max_it), *reason is the
+ * last attempt's, the first attempt's is out[6] of sns_get_counters.  Running out of
+ * iterations (DIVERGED_ITS) is never retried.                                    */
 int sns_krylov_solve(sns_handle h, const double* b_dev, double* x_dev,
                      int* its, int* reason, double* rnorm);
 /* solve_stokes_problem (:197-218): assemble + lift + KSP; U_dev receives U.   */
@@ -241,8 +247,14 @@ typedef struct {
 } sns_timings;
 int sns_get_timings(sns_handle h, sns_timings* t);
 /* debug counters of the LAST Krylov solve: out[0] = host<->device synchronisations (stream / event waits),
- * out[1] = all-reduces, out[2] = neighbour (halo) exchanges, out[3] = Krylov iterations since reset_timings */
-int sns_get_counters(sns_handle h, int64_t out[4]);
+ * out[1] = all-reduces, out[2] = neighbour (halo) exchanges; out[3] = Krylov iterations since reset_timings,
+ * out[4] = damping retries since reset_timings, out[5] = current damping factor x 1e6 (1000000 = no retry so far),
+ * out[6] = reason of the first attempt of the last solve if it was retried (else 0), out[7] = reserved (0) */
+int sns_get_counters(sns_handle h, int64_t out[8]);
+/* communicator of the handle: out[0] = transport (0 none, 1 RCCL, 2 in-process team), out[1] = this rank,
+ * out[2] = ranks the handle was attached with, out[3] = ranks RCCL itself reports (ncclCommCount; 0 without RCCL):
+ * bench.py prints it so that "did RCCL see N ranks" can be read off the result line */
+int sns_comm_info(sns_handle h, int32_t out[4]);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot)     */

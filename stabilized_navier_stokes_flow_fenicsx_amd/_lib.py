@@ -35,6 +35,7 @@ class SnsOptions(C.Structure):
         ("amg_fine_cycle", C.c_int),
         ("amg_nu_l1_pre", C.c_int),
         ("amg_nu_l1_post", C.c_int),
+        ("amg_retry_damping", C.c_int),
     ]
 
 
@@ -87,6 +88,7 @@ _SIGNATURES = [
     ("sns_export", C.c_int, [_H, C.c_int, _P, C.c_int64]),
     ("sns_get_timings", C.c_int, [_H, C.POINTER(SnsTimings)]),
     ("sns_get_counters", C.c_int, [_H, C.POINTER(C.c_int64)]),
+    ("sns_comm_info", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("sns_reset_timings", C.c_int, [_H]),
     ("sns_time_kernels", C.c_int, [_H, C.c_int]),
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

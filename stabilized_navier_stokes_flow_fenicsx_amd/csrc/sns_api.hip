@@ -127,8 +127,10 @@ struct sns_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_x = nullptr, ev_side = nullptr;
     bool no_overlap = false;
+    bool team_overlap = false;                       // SNS_TEAM_OVERLAP: the team transport takes the two-stream path too (tests)
     double damping_backoff = 1.0;                    // < 1 after a failed AMG-preconditioned solve: all level dampings scaled (krylov())
-    bool no_windows = false;                         // SNS_NO_WINDOWS: A/B switch for the windowed LDS gathers                          // extra partial-sum blocks of the boundary pass of a split SpMV+dot
+    int64_t ctr_retries = 0;                         // damping retries since sns_reset_timings
+    int last_first_reason = 0;                       // reason of the FIRST attempt of the last solve (0 = no retry happened)
     std::unique_ptr<Comm> comm;
     // distributed coarsest level: global dense inverse, replicated on every rank
     int cg_maxn = 0;                              // padded owned coarsest nodes per rank
@@ -371,7 +373,10 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
     s2.mode = 2;
     s2.partial_off = gs;
     if (MODE == SPMV_AX_DOT) h->bnd_dot_blocks = (h->n_bnd + 31) / 32;
-    if (c->nccl) {
+    if (c->nccl || h->team_overlap) {
+        // (team transport with SNS_TEAM_OVERLAP=1: the same two-stream choreography -- interior pass on the side
+        // stream, event joins, per-launch timing events on that stream -- over the emulated exchange, so that the
+        // stream dependencies of the production path are exercised on a 1-GPU box)
         if (!h->side_stream) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -388,7 +393,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         pass(s2);                                                    // boundary rows
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_side, 0));       // y complete for whatever comes next
     } else {
-        // team transport (tests): the exchange synchronises the host anyway; same two passes, one stream
+        // team transport (tests, default): the exchange synchronises the host anyway; same two passes, one stream
         SNS_TRY(halo_exchange(h, xe));
         pass(s1);
         pass(s2);
@@ -1730,19 +1735,23 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
     h->ctr_host_syncs = h->ctr_allreduce = h->ctr_exchange = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    // A failed solve under the AMG preconditioner is retried ONCE with every level's block-Jacobi damping scaled by 0.7
-    // (from the same initial guess): the damping estimate (|lambda|max of Dinv A + a growth check on the dominant mode)
-    // is not a bound for a non-symmetric operator, and at cell Reynolds numbers of 5-10 a slightly over-relaxed
-    // smoother is what breaks BiCGStab down (measured: jittered 648 k-tet duct, Re 200: auto damping fails after 218
-    // iterations, 0.7 x converges).  The smaller damping is kept for the later Jacobians of the handle.  Not in the
-    // reference (PETSc reports the failed reason and stops); converging solves never see it.
-    const bool can_retry = h->opt.pc_type == SNS_PC_AMG && h->damping_backoff > 0.4;
+    // A solve that BREAKS DOWN (or produces NaN/Inf) under the AMG preconditioner is retried ONCE, from the same initial
+    // guess, with every level's block-Jacobi damping scaled by 0.7 (opt.amg_retry_damping, default on): the damping
+    // estimate (|lambda|max of Dinv A + a growth check on the dominant mode) is not a bound for a non-symmetric
+    // operator, and at cell Reynolds numbers of 5-10 a slightly over-relaxed smoother is what breaks BiCGStab down
+    // (measured: jittered 648 k-tet duct, Re 200: auto damping fails after 218 iterations, 0.7 x converges).  A solve
+    // that merely runs out of iterations (DIVERGED_ITS) is NOT retried: like PETSc, the reason is reported and that is
+    // it.  The smaller damping is kept for the later Jacobians of the handle until sns_set_options is called; the
+    // retry count and the current factor are visible through sns_get_counters.  *its is the sum over both attempts
+    // (<= 2 ksp_max_it).  Not in the reference; converging solves never see it.
+    const bool can_retry = h->opt.pc_type == SNS_PC_AMG && h->opt.amg_retry_damping != 0 && h->damping_backoff > 0.4;
     double* x0 = nullptr;
     if (can_retry) {
         SNS_TRY(get_vec(h, 14, &x0));
         HIP_TRY(hipMemcpyAsync(x0, x, nred_of(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     int its_total = 0;
+    h->last_first_reason = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
         if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
@@ -1751,7 +1760,10 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
         else { set_error("bad ksp_type"); return SNS_E_ARG; }
         SNS_TRY(rc);
         its_total += *its;
-        if (*reason > 0 || !can_retry || attempt == 1) break;
+        const bool retryable = *reason == SNS_KSP_DIVERGED_BREAKDOWN || *reason == SNS_KSP_DIVERGED_NANORINF;
+        if (!retryable || !can_retry || attempt == 1) break;
+        h->last_first_reason = *reason;
+        ++h->ctr_retries;
         h->damping_backoff *= 0.7;
         if (h->opt.monitor)
             std::printf("  KSP failed (reason %d after %d iterations): retrying with the smoother damping scaled by %.2f\n",
@@ -1826,6 +1838,7 @@ void sns_default_options(sns_options* o) {
     o->amg_fine_cycle = 0;
     o->amg_nu_l1_pre = 0;
     o->amg_nu_l1_post = 0;
+    o->amg_retry_damping = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -2043,6 +2056,11 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows) ||
                                         (o->amg_post_exchange != h->opt.amg_post_exchange);
     h->opt = *o;
+    if (h->damping_backoff != 1.0) {                 // a retry's stronger damping does not outlive an options call
+        h->damping_backoff = 1.0;
+        h->pc_ready = false;
+        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }
+    }
     if (sweep_exchange_changed) {
         // rank-local sweeps rely on ghost tails that are never written (zero); sweeps with exchanges fill them
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2136,6 +2154,7 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
         SNS_TRY(dev_upload(&h->bnd_rows, rows, nullptr));
         SNS_TRY(dev_upload(&h->bnd_flag, flag, nullptr));
         h->no_overlap = std::getenv("SNS_NO_OVERLAP") != nullptr;
+        h->team_overlap = std::getenv("SNS_TEAM_OVERLAP") != nullptr;
     }
     if (!c.active()) {
         // no transport: the per-rank hierarchy must not reference ghost dofs at all
@@ -2359,12 +2378,32 @@ int sns_export(sns_handle h, int what, void* dst, int64_t nbytes) {
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)need, hipMemcpyDeviceToDevice, h->stream));
     return sync_stream(h);
 }
-int sns_get_counters(sns_handle h, int64_t out[4]) {
+int sns_get_counters(sns_handle h, int64_t out[8]) {
     if (!h || !out) return SNS_E_ARG;
     out[0] = h->last_ctr[0];
     out[1] = h->last_ctr[1];
     out[2] = h->last_ctr[2];
     out[3] = h->tm.ksp_its;
+    out[4] = h->ctr_retries;
+    out[5] = (int64_t)std::llround(h->damping_backoff * 1e6);
+    out[6] = h->last_first_reason;
+    out[7] = 0;
+    return SNS_OK;
+}
+int sns_comm_info(sns_handle h, int32_t out[4]) {
+    if (!h || !out) return SNS_E_ARG;
+    out[0] = out[1] = out[3] = 0;
+    out[2] = 1;
+    const Comm* c = h->comm.get();
+    if (!c) return SNS_OK;
+    out[0] = c->nccl ? 1 : (c->team ? 2 : 0);
+    out[1] = c->rank;
+    out[2] = c->nranks;
+    if (c->nccl) {
+        int cnt = 0;
+        NCCL_TRY(ncclCommCount(c->nccl, &cnt));
+        out[3] = cnt;
+    }
     return SNS_OK;
 }
 int sns_get_timings(sns_handle h, sns_timings* t) {
@@ -2376,6 +2415,7 @@ int sns_get_timings(sns_handle h, sns_timings* t) {
 int sns_reset_timings(sns_handle h) {
     if (!h) return SNS_E_ARG;
     h->tm = sns_timings{};
+    h->ctr_retries = 0;
     for (int i = 0; i < 4; ++i) { h->kt_ms[i] = 0; h->kt_calls[i] = 0; }
     return SNS_OK;
 }

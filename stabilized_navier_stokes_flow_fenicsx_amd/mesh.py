@@ -285,6 +285,64 @@ def delaunay_duct_mesh(n: int = 8, x_outlet: float = 2.0, *, seed: int = 0, min_
                    meta={"lo": lo, "hi": hi, "tags": tags, "kind": "duct"})
 
 
+def delaunay_channel_mesh(n: int = 16, *, length: float = 4.0, seed: int = 0, lattice: str = "bcc",
+                          inner_half_width: float = 0.25) -> TetMesh:
+    """Unstructured stand-in for the gmsh mesh of image2gmsh3D.py:445-486: Delaunay tetrahedralisation (scipy) of a
+    slightly jittered body-centred (``lattice="bcc"``: nearly regular tets, what a production mesher delivers) or
+    cubic (``"cubic"``: sliver-rich) lattice on the 4x1x1 channel, h = 1/n; facet tags of the two-stream channel
+    (CHANNEL_TAGS; inlet facets by the position of their centroid, like ``channel_mesh``).  Nodes are ordered
+    x-slowest (sorted by plane) so that x-slabs stay contiguous id ranges."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    h = 1.0 / n
+    nx = int(round(length / h))
+    xs, ys, zs = np.linspace(0, length, nx + 1), np.linspace(-0.5, 0.5, n + 1), np.linspace(-0.5, 0.5, n + 1)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    I, J, K = np.meshgrid(np.arange(nx + 1), np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    d = rng.uniform(-0.25, 0.25, size=pts.shape) * h
+    d[:, 0][((I == 0) | (I == nx)).ravel()] = 0.0
+    d[:, 1][((J == 0) | (J == n)).ravel()] = 0.0
+    d[:, 2][((K == 0) | (K == n)).ravel()] = 0.0
+    if lattice == "bcc":
+        d *= 0.2
+        Xc, Yc, Zc = np.meshgrid(0.5 * (xs[1:] + xs[:-1]), 0.5 * (ys[1:] + ys[:-1]), 0.5 * (zs[1:] + zs[:-1]), indexing="ij")
+        cen_pts = np.stack([Xc.ravel(), Yc.ravel(), Zc.ravel()], axis=1)
+        cen_pts = cen_pts + rng.uniform(-0.05, 0.05, size=cen_pts.shape) * h
+        pts = np.concatenate([pts + d, cen_pts])
+    elif lattice == "cubic":
+        pts = pts + d
+    else:
+        raise ValueError("lattice must be 'bcc' or 'cubic'")
+    order = np.lexsort((pts[:, 2], pts[:, 1], np.round(pts[:, 0] / (0.5 * h))))       # x-slowest node ids
+    pts = pts[order]
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    X4 = pts[tets]
+    vol = np.abs(np.linalg.det(np.stack([X4[:, 1] - X4[:, 0], X4[:, 2] - X4[:, 0], X4[:, 3] - X4[:, 0]], axis=2))) / 6.0
+    tets = tets[vol > 1e-9 * h ** 3].astype(np.int32)
+    if len(np.unique(tets)) != len(pts):
+        raise ValueError("delaunay_channel_mesh: a point lost all its tets")
+    fac = _boundary_facets(tets)
+    lo, hi = (0.0, -0.5, -0.5), (float(length), 0.5, 0.5)
+    tags = dict(CHANNEL_TAGS)
+
+    def tagger(on, cent):
+        t = np.full(fac.shape[0], -1)
+        for k_ in ("ylo", "yhi", "zlo", "zhi"):
+            t[on[k_]] = tags["wall"]
+        inner = (np.abs(cent[:, 1]) < inner_half_width) & (np.abs(cent[:, 2]) < inner_half_width)
+        t[on["xlo"] & inner] = tags["inlet_1"]
+        t[on["xlo"] & ~inner] = tags["inlet_2"]
+        t[on["xhi"]] = tags["outlet"]
+        return t
+
+    ft = _tag_box_facets(pts, fac, lo, hi, tagger)
+    if (ft < 0).any():
+        raise ValueError("delaunay_channel_mesh: dropping slivers opened the mesh")
+    return TetMesh(pts, tets, fac, ft.astype(np.int32), name="channel-delaunay",
+                   meta={"lo": lo, "hi": hi, "tags": tags, "kind": "channel", "inner_half_width": inner_half_width, "h": h})
+
+
 DFG_TAGS = {"inlet": 2, "outlet": 3, "wall": 4, "obstacle": 5}   # DFG_3D_Validation.py:104-109
 
 

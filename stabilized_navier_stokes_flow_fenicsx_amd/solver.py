@@ -318,9 +318,16 @@ class FlowProblem:
 
     def counters(self):
         """Debug counters of the last Krylov solve: host syncs, all-reduces, halo exchanges (+ ksp its since reset)."""
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 8)()
         check(self.lib.sns_get_counters(self.h, c))
-        return dict(host_syncs=c[0], allreduces=c[1], exchanges=c[2], ksp_its=c[3])
+        return dict(host_syncs=c[0], allreduces=c[1], exchanges=c[2], ksp_its=c[3], damping_retries=c[4],
+                    damping_factor=c[5] * 1e-6, first_attempt_reason=c[6])
+
+    def comm_info(self):
+        """Transport / rank / ranks of the handle's communicator; ``rccl_ranks`` is what ncclCommCount reports."""
+        c = (C.c_int32 * 4)()
+        check(self.lib.sns_comm_info(self.h, c))
+        return dict(transport={0: "none", 1: "rccl", 2: "team"}[c[0]], rank=c[1], nranks=c[2], rccl_ranks=c[3])
 
     def reset_timings(self):
         check(self.lib.sns_reset_timings(self.h))

@@ -215,3 +215,54 @@ def test_slab_part_without_global_mesh_matches_global_partition(cells, length, n
         for k in ("l2g", "tet_ids", "bc_mask", "bc_val", "neighbors", "send_ptr", "send_idx", "recv_ptr", "recv_idx"):
             assert np.array_equal(getattr(a, k), getattr(c, k)), k
         assert np.array_equal(a.mesh.tets, c.mesh.tets) and np.array_equal(a.mesh.points, c.mesh.points)
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    """bench.py as a plain command (what the driver types), from the repo root; returns (rc, stdout, stderr)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` as a plain command starts TWO ranks itself (torch.distributed.run on 127.0.0.1) --
+    here in --dry-run mode: rendezvous, the per-rank slab partition, the halo plans checked by a real exchange of
+    global node ids, the boundary-row split, one all-reduce -- all on gloo, no HIP call.  The line says n_gpus 2."""
+    import json
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"])
+    assert rc == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None
+    c = d["config"]
+    assert c["halo_plans_consistent_ranks"] == 2                       # both ranks received exactly their ghosts' ids
+    assert c["owned_nodes_total"] == 25 * 7 * 7                        # every node owned once
+    assert 2 * 49 <= c["boundary_rows_total"] < 4 * 49 and c["neighbours_of_rank0"] == [1]
+    # an RCB-partitioned config through the same path
+    rc, out, err = _run_bench(["--gpus", "3", "--dry-run", "--config", "3", "--cells", "6,6,6"])
+    assert rc == 0, err[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 3 and d["config"]["halo_plans_consistent_ranks"] == 3 and d["config"]["owned_nodes_total"] == 343
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert rc == 2 and "WORLD_SIZE" in err and out.strip() == ""
+
+
+def test_bench_watchdog_turns_a_stalled_rank_into_a_nonzero_exit():
+    """A rank that stops making progress exits non-zero by itself (no re-exec); the launcher passes the failure on."""
+    import time
+    t0 = time.time()
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"],
+                              {"SNS_DRYRUN_STALL_RANK": "1", "SNS_WATCHDOG_S": "2"}, timeout=120)
+    assert rc != 0 and "watchdog: rank 1" in err
+    assert time.time() - t0 < 100

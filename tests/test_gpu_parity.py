@@ -417,12 +417,16 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
 
 @pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab"), (4, "duct-rep"),
                                          (5, "cavity-rep")])
-def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
+def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
     """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
     exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
     GPU over the in-process team transport; RCCL only replaces the transport on a multi-GPU node."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
     from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    if kind == "slab":
+        # the production (RCCL) choreography of a level-0 pass -- interior rows on a second, low-priority stream,
+        # event joins with the halo on the handle's stream -- over the emulated exchange (read at attach time)
+        monkeypatch.setenv("SNS_TEAM_OVERLAP", "1")
     # "-rep": a small coarsest size forces a REPLICATED tail of the hierarchy from level 1 on (every rank holds the
     # global level-1 operator, all-gathered values, and cycles the levels below redundantly without exchanges)
     kw = dict(amg_coarse_size=24, amg_replicate_rows=1 << 20) if kind.endswith("-rep") else {}
@@ -465,8 +469,8 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
         c = P.counters()
         sizes = P.sizes()
         if kind == "slab":
-            # bench.py times every fine-level SpMV launch with HIP events (sns_time_kernels); in a partitioned run the
-            # interior passes run on the side stream of the overlapped halo -- the event pairs must resolve there too
+            # bench.py times every fine-level SpMV launch with HIP events (sns_time_kernels); with SNS_TEAM_OVERLAP the
+            # interior passes run on the side stream like under RCCL -- the event pairs must resolve there too
             P.reset_timings()
             P.time_kernels(True)
         w, n = P.newton_solve(U.clone())
@@ -494,6 +498,47 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind):
     assert outs[0][2].its <= 2 * rs.its + 4                                   # coarse correction stays global
     if kw:
         assert outs[0][5] >= 3                                                # fine, distributed level 1, replicated tail
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_two_stream_halo_overlap_matches_exchange_then_full_pass(gpu, nranks, monkeypatch):
+    """exchange_and_spmv's production branch (interior rows on the side stream while the halo is in flight, boundary
+    rows after the unpack, ev_x / ev_side joins, split partial sums of the fused SpMV+dot) against its documented
+    fallback SNS_NO_OVERLAP=1 (exchange, then one full pass on one stream): same iteration counts, same fields.  RCCL
+    with N > 1 ranks cannot run on a 1-GPU box; the team transport takes the same branch with SNS_TEAM_OVERLAP=1."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    cells, length, Re = (48, 12, 12), 4.0, 40.0
+
+    def solve(env):
+        for k in ("SNS_TEAM_OVERLAP", "SNS_NO_OVERLAP"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv(env, "1")
+        team = Team(nranks)
+
+        def work(rank, team):
+            P = gpu.from_part(PT.duct_slab_part(cells, length, rank, nranks), group=team, reynolds=Re)
+            U, r = P.stokes_solve()
+            w, n = P.newton_solve(U.clone())
+            x = torch.arange(P.ndof, dtype=torch.float64, device=P.device).remainder(7.0)
+            x[4 * P.n_owned:] = 0.0
+            y = P.spmv(x)[:4 * P.n_owned].cpu().numpy()
+            out = (P.part, U.cpu().numpy(), r, w.cpu().numpy(), n, y)
+            P.close()
+            return out
+
+        outs = team.run(work)
+        team.close()
+        return outs
+
+    a = solve("SNS_TEAM_OVERLAP")
+    b = solve("SNS_NO_OVERLAP")
+    for (pa, Ua, ra, wa, na, ya), (pb, Ub, rb, wb, nb_, yb) in zip(a, b):
+        no = 4 * pa.n_owned
+        assert ra.reason > 0 and na.reason > 0
+        assert (ra.its, na.its, na.ksp_its) == (rb.its, nb_.its, nb_.ksp_its)
+        assert np.array_equal(ya, yb)                                   # the operator pass itself: bitwise
+        assert rel(Ua[:no], Ub[:no]) < 1e-10 and rel(wa[:no], wb[:no]) < 1e-10
 
 
 @pytest.mark.parametrize("opts", [dict(amg_post_exchange=0, amg_replicate_rows=0),
@@ -1065,13 +1110,36 @@ def test_fgmres_under_the_partitioned_hierarchy(gpu, nranks):
 def test_damping_backoff_rescues_a_failed_linear_solve(gpu):
     """At cell Reynolds numbers of 5-10 the automatically chosen block-Jacobi damping can be slightly too large for the
     non-symmetric Jacobian and BiCGStab breaks down (jittered 648 k-tet duct at Re 200: the first Newton step's solve
-    fails after ~200 iterations).  krylov() retries such a solve once with every level's damping scaled by 0.7 and
-    keeps the smaller damping; the Newton loop then converges as with a hand-set amg_omega = 0.6."""
+    fails after ~200 iterations).  krylov() retries a solve that ends in BREAKDOWN / NANORINF once with every level's
+    damping scaled by 0.7 and keeps the smaller damping until the next sns_set_options; the Newton loop then converges
+    as with a hand-set amg_omega = 0.6.  Exactly one retry happens, it is visible in the counters, running out of
+    iterations is never retried, and with amg_retry_damping = 0 the failure is reported as PETSc would."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
     m = M.duct_mesh((120, 30, 30), 4.0, jitter=0.2)
     P = gpu(m, B.duct_bcs(m), reynolds=200.0, ksp_max_it=1500)
     U, r = P.stokes_solve()
+    assert r.reason > 0
+    P.reset_timings()
+    # (a) no retry: the reference's behaviour -- the linear solve fails, SNES reports DIVERGED_LINEAR_SOLVE
+    P.set_options(amg_retry_damping=0)
+    w0, n0 = P.newton_solve(U.clone())
+    c0 = P.counters()
+    assert n0.reason == -3 and c0["damping_retries"] == 0 and c0["damping_factor"] == 1.0
+    # (b) running out of iterations is not a breakdown: reported, not retried, its == ksp_max_it
+    P.set_options(amg_retry_damping=1, ksp_max_it=5)
+    P.jacobian(U, "ns")
+    _, k = P.krylov_solve(P.residual(U, "ns"))
+    c1 = P.counters()
+    assert k.reason == -3 and k.its == 5 and c1["damping_retries"] == 0 and c1["first_attempt_reason"] == 0
+    # (c) default: exactly one retry over the whole Newton solve, after a breakdown, and the factor is kept
+    P.set_options(ksp_max_it=1500)
+    P.reset_timings()
     w, n = P.newton_solve(U.clone())
-    assert r.reason > 0 and n.reason > 0 and n.its <= 6
+    c2 = P.counters()
+    assert n.reason > 0 and n.its <= 6
+    assert c2["damping_retries"] == 1 and abs(c2["damping_factor"] - 0.7) < 1e-9
     assert float(P.residual(w, "ns").norm()) < 1e-8
+    # (d) sns_set_options resets the factor
+    P.set_options(ksp_max_it=1500)
+    assert P.counters()["damping_factor"] == 1.0
     P.close()

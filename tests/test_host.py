@@ -331,13 +331,14 @@ def test_bench_helpers_without_gpu():
     bench = importlib.import_module("bench")
     after = {m for m in sys.modules if m == "oracle" or m.startswith("oracle.")}
     assert after == before                                   # cpu_baseline imports the oracle lazily, only when it runs
-    t = bench.pmc_traffic("k_spmv_f32<2, 1")
+    t, src = bench.pmc_traffic("k_spmv_f32<2, 1")
     assert t is not None and 2.0e9 < t < 3.0e9               # 2.14 GB algorithmic, ~2.4 GB measured
-    t2 = bench.pmc_traffic("k_spmv_lp<2, 1, 0, 2")          # round 2: fp16 Jacobi sweep, 1.24 GB algorithmic
+    assert src.startswith("profiles/") and "pmc" in src      # the line names the committed CSVs the figure is read from
+    t2, _ = bench.pmc_traffic("k_spmv_lp<2, 1, 0, 2")       # round 2: fp16 Jacobi sweep, 1.24 GB algorithmic
     assert t2 is not None and 1.2e9 < t2 < 1.8e9
-    t3 = bench.pmc_traffic("k_spmv<0, 1, 1, 0>")             # fp64 Krylov operator: 3.51 GB algorithmic
+    t3, _ = bench.pmc_traffic("k_spmv<0, 1, 1, 0>")          # fp64 Krylov operator: 3.51 GB algorithmic
     assert t3 is not None and 3.4e9 < t3 < 3.7e9
-    assert bench.pmc_traffic("no_such_kernel") is None
+    assert bench.pmc_traffic("no_such_kernel") == (None, None)
     assert bench.HBM_PEAK_GBS == 8000.0
 
 
