@@ -265,12 +265,6 @@ int sns_get_kernel_times(sns_handle h, double ms_total[4], int64_t calls[4]);
  * the average duration in ms.                                                  */
 int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
 int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
-/* interleaved A/B timing of two kernel variants in one process; ms_out[v] = average launch ms of variant v:
- * which 0 = fp64 y=Ax default vs non-temporal matrix loads, 3 = fp64 y=Ax production (first 16 blocks of a row requested
- * up-front) vs the stepped loop it replaced,
- * 1 = low-precision Jacobi sweep fp16 row-scaled vs fp32 (both copies must exist: SNS_BOTH_LP=1 at pc_setup)  */
-int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]);
-
 /* ---- batched particle tracing (next row after the solve path; replaces the per-seed
  *      solve_ivp(RK45) of NavierStokes/streamtrace.py:208-232, :357-383) ---------------
  * One lane per seed: scipy's RK45 (same tableau, controller and initial step; rtol/atol as

@@ -94,7 +94,6 @@ _SIGNATURES = [
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("sns_bench_spmv", C.c_int, [_H, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     ("sns_bench_assemble", C.c_int, [_H, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_double)]),
-    ("sns_bench_variants", C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("sns_streamtrace", C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
@@ -119,6 +118,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "sns_bench_variants"):           # experiment build only (make HARNESS=1, csrc/sns_harness.h)
+        lib.sns_bench_variants.restype = C.c_int
+        lib.sns_bench_variants.argtypes = [_H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _lib = lib
     return lib
 

@@ -149,7 +149,7 @@ def write_xdmf(path_noext: str, msh, name: str, values: np.ndarray):
     """P1 nodal field as ``<path>.xdmf`` + ``<path>.h5`` -- ``XDMFFile.write_mesh`` + ``write_function`` of
     :333-341.  Same container layout as dolfinx 0.9 writes: ``/Mesh/mesh/geometry`` (N x gdim float64),
     ``/Mesh/mesh/topology`` (E x nodes-per-cell int64), ``/Function/<name>/0`` (N x ncomp float64; a scalar is
-    N x 1), the light data pointing into it with ``Format="HDF"`` items -- so the reference's consumer
+    N x 1, a 2-D vector is padded to N x 3 with uz = 0 as dolfinx does), the light data pointing into it with ``Format="HDF"`` items -- so the reference's consumer
     (streamtrace.py:87-96: ``h5f["Function"][name]["0"]``) and ParaView open it unchanged.  h5py does not exist
     offline; the container is written by ``h5lite`` (file-format spec, v1 objects)."""
     from .h5lite import H5Writer
@@ -158,6 +158,9 @@ def write_xdmf(path_noext: str, msh, name: str, values: np.ndarray):
     cells = msh.tris if dim == 2 else msh.tets
     values = np.asarray(values, dtype=np.float64)
     vals2 = values.reshape(len(values), -1)
+    if vals2.shape[1] == 2:
+        # dolfinx' XDMF write_function pads a 2-component vector to 3 (XDMF has no 2-vector attribute): N x 3, uz == 0
+        vals2 = np.concatenate([vals2, np.zeros((len(vals2), 1))], axis=1)
     ncomp = vals2.shape[1]
     w = H5Writer()
     w.dataset("/Mesh/mesh/geometry", np.asarray(msh.points, dtype=np.float64))
@@ -420,10 +423,11 @@ def dfg_2d_main(argv=None):
     against the script's constants (:195-214), XDMF output (:216-238).
 
     ``<msh file>`` is a gmsh ASCII file of dfg_pillar_2D.geo, or ``builtin[:level]`` for the gmsh-free mesh of the
-    same geometry (mesh2d.dfg_2d_mesh).  The Stokes pressure is rescaled by nu before it seeds Newton (the unit-
-    viscosity pressure is 1/nu times too large for the NS problem; on meshes coarser than the .geo's the full
-    Newton step from the unscaled field diverges, in the oracle's LU-Newton as well); SNS_DFG_RAW_GUESS=1 keeps
-    the field exactly as the script passes it on."""
+    same geometry (mesh2d.dfg_2d_mesh).  Newton starts from the Stokes field exactly as the script passes it on
+    (:141-187).  Only if that solve does NOT converge is it repeated with the Stokes pressure rescaled by nu (the unit-
+    viscosity pressure is 1/nu times too large for the NS problem; on meshes coarser than the .geo's the full Newton
+    step from the unscaled field diverges, in the oracle's LU-Newton as well) -- a documented fallback, announced on
+    stdout; SNS_DFG_RESCALED_GUESS=1 goes straight to the rescaled guess."""
     from . import mesh2d as M2
     from .solver import solve_navier_stokes
     argv = sys.argv if argv is None else argv
@@ -443,9 +447,18 @@ def dfg_2d_main(argv=None):
     U, res = P.stokes_solve()
     if _rank() == 0:
         print("Solved Stokes Flow", flush=True)
-    if os.environ.get("SNS_DFG_RAW_GUESS", "0") != "1":
-        U.view(-1, 4)[:, 3] *= nu
-    w, u, p = solve_navier_stokes(P, U.clone(), _rank(), continuation=_continuation())
+    rescale_first = os.environ.get("SNS_DFG_RESCALED_GUESS", "0") == "1"
+    U0 = U.clone()
+    if rescale_first:
+        U0.view(-1, 4)[:, 3] *= nu
+    w, u, p = solve_navier_stokes(P, U0.clone(), _rank(), continuation=_continuation())
+    if P.last_newton.reason <= 0 and not rescale_first:
+        if _rank() == 0:
+            print(f"Newton from the unit-viscosity Stokes field did not converge (reason {P.last_newton.reason}): "
+                  "repeating with the Stokes pressure rescaled by nu", flush=True)
+        U0 = U.clone()
+        U0.view(-1, 4)[:, 3] *= nu
+        w, u, p = solve_navier_stokes(P, U0, _rank(), continuation=_continuation())
     wg = _to_global_host(P, w)
     cd, cl = M2.drag_lift_2d(msh, wg, nu)
     if _rank() == 0:

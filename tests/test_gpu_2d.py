@@ -146,7 +146,17 @@ def test_dfg2d_series_converges_to_the_reference_constants():
     el = [abs(cl - M2.DFG2D_CL_REF) for _, _, _, cl, _ in out]
     assert ed[1] < 0.6 * ed[0] and ed[2] < 0.6 * ed[1] and ed[3] < 0.6 * ed[2]
     assert ed[3] < 0.005 * M2.DFG2D_CD_REF
-    assert el[3] < 0.10 * M2.DFG2D_CL_REF and el[3] < el[0]
+    assert el[3] < 0.02 * M2.DFG2D_CL_REF and el[3] < el[0]           # observed -0.41 % at level 16
+    # Richardson extrapolation with the OBSERVED order, from the series alone (levels 4 / 8 / 16, h halves per level;
+    # the reference value does not enter): C* = c16 + (c16 - c8) q / (1 - q), q = (c16 - c8) / (c8 - c4).  Observed:
+    # q = 0.454 (order 1.14), C* = 5.57989 -- 3.6e-4 (6e-5 relative) from the reference's 5.57953523384.
+    c4, c8, c16 = (o[2] for o in out[1:])
+    q = (c16 - c8) / (c8 - c4)
+    cd_star = c16 + (c16 - c8) * q / (1.0 - q)
+    print(f"  Richardson (levels 4/8/16): q {q:.4f} (observed order {-np.log2(q):.2f}), C_d* {cd_star:.6f} "
+          f"({cd_star - M2.DFG2D_CD_REF:+.2e} from the reference constant)")
+    assert 0.35 < q < 0.6
+    assert abs(cd_star - M2.DFG2D_CD_REF) < 5e-4
 
 
 def test_dfg2d_constants_on_the_3d_tet_path():
@@ -186,6 +196,15 @@ def test_dfg2d_constants_on_the_3d_tet_path():
         assert ed[1] < 0.6 * ed[0] and ed[2] < 0.7 * ed[1]
         assert ed[2] < 0.0025 * M2.DFG2D_CD_REF
         assert abs(out[corrected][2][1] - M2.DFG2D_CL_REF) < 0.06 * M2.DFG2D_CL_REF
+        # first-order extrapolation from levels 4 and 8 (the functional is first order in h; the slab series is too
+        # short and too irregular for an observed-order fit): 2 c8 - c4 within 0.1 % of the reference constant
+        # (observed: literal +0.087 %, consistent +0.020 %)
+        cd_star = 2.0 * out[corrected][2][0] - out[corrected][1][0]
+        print(f"  3-D path, {'consistent' if corrected else 'literal'}: first-order extrapolation C_d* {cd_star:.6f} "
+              f"({100 * (cd_star / M2.DFG2D_CD_REF - 1):+.3f} %)")
+        assert abs(cd_star - M2.DFG2D_CD_REF) < 1e-3 * M2.DFG2D_CD_REF
+    # both readings of dot(u, grad(.)) (:241, :247) converge to the same constant: the reference-held numbers pin the
+    # Galerkin terms, BC semantics, assembly, solver and functional, and cannot tell the two readings apart
     for (cd0, _), (cd1, _) in zip(out[0], out[1]):
         assert cd1 < M2.DFG2D_CD_REF < cd0                      # the two forms bracket the reference value on every level
 

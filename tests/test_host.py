@@ -418,8 +418,13 @@ def test_xdmf_output_is_the_hdf5_container_the_reference_reads(tmp_path):
                                              (m.num_tets, 4), "i8"), m.tets)
     # 2-D meshes (lid-driven / DFG-2D scripts) and groups with many children
     m2 = M2.rectangle_mesh(3)
-    D.write_xdmf(str(tmp_path / "c"), m2, "Velocity", rng.normal(size=(m2.num_nodes, 2)))
+    v2 = rng.normal(size=(m2.num_nodes, 2))
+    D.write_xdmf(str(tmp_path / "c"), m2, "Velocity", v2)
     assert R.H5File(str(tmp_path / "c.h5"))["Mesh/mesh/topology"].shape == (18, 3)
+    # a 2-D vector is padded to three components (uz = 0), as dolfinx' XDMF write_function does
+    f2 = R.H5File(str(tmp_path / "c.h5"))["Function"]["Velocity"]["0"]
+    assert f2.shape == (m2.num_nodes, 3) and np.array_equal(f2[:, :2], v2) and np.all(f2[:, 2] == 0.0)
+    assert f'Dimensions="{m2.num_nodes} 3"' in open(tmp_path / "c.xdmf").read()
     from stabilized_navier_stokes_flow_fenicsx_amd.h5lite import H5Writer, read_datasets
     w = H5Writer()
     for i in range(37):
