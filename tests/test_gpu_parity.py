@@ -519,10 +519,13 @@ def test_two_stream_halo_overlap_matches_exchange_then_full_pass(gpu, nranks, mo
         def work(rank, team):
             P = gpu.from_part(PT.duct_slab_part(cells, length, rank, nranks), group=team, reynolds=Re)
             U, r = P.stokes_solve()
-            w, n = P.newton_solve(U.clone())
+            # one operator pass with the (state-independent) Stokes matrix: the split passes compute every row with
+            # the arithmetic of the full pass, so this is bitwise (the Newton iterates below are not: the split
+            # SpMV+dot sums its partials in another order)
             x = torch.arange(P.ndof, dtype=torch.float64, device=P.device).remainder(7.0)
             x[4 * P.n_owned:] = 0.0
             y = P.spmv(x)[:4 * P.n_owned].cpu().numpy()
+            w, n = P.newton_solve(U.clone())
             out = (P.part, U.cpu().numpy(), r, w.cpu().numpy(), n, y)
             P.close()
             return out
