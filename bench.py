@@ -324,6 +324,31 @@ def dry_run(args, cfg, cells, length, world, rank):
     return 0 if ok else 4
 
 
+def halo_overlap_selfcheck(P, world):
+    """First contact of the overlapped halo path with a real multi-rank RCCL communicator: one operator pass with the
+    interior / boundary split on two streams against the same pass as exchange-then-full-pass (halo_overlap = 0).
+    Both compute every row with the same arithmetic, so the results must agree BITWISE on every rank; if they do
+    not, the run continues on the fallback and the line says so."""
+    import torch
+    import torch.distributed as dist
+    x = torch.arange(P.ndof, dtype=torch.float64, device=P.device).remainder(11.0) - 5.0
+    x[4 * P.n_owned:] = 0.0
+    no = 4 * P.n_owned
+    if os.environ.get("SNS_NO_OVERLAP"):
+        return "SNS_NO_OVERLAP set: exchange-then-full-pass"
+    P.set_options(halo_overlap=0)
+    y0 = P.spmv(x.clone())[:no].clone()
+    P.set_options(halo_overlap=1)
+    y1 = P.spmv(x.clone())[:no].clone()
+    bad = torch.tensor([0.0 if torch.equal(y0, y1) else 1.0], dtype=torch.float64, device=P.device)
+    if world > 1:
+        dist.all_reduce(bad)
+    if float(bad) > 0:
+        P.set_options(halo_overlap=0)
+        return f"MISMATCH on {int(bad)} rank(s): overlapped halo disabled, exchange-then-full-pass used"
+    return "overlapped interior/boundary split == exchange-then-full-pass, bitwise, on every rank"
+
+
 def timed_newton_steps(P, U, steps, warmup, world):
     """W untimed + K timed Newton iterations of a real sequence from the Stokes solution U (restarted when it has
     converged); barrier + synchronize on both sides, MAX over ranks.  Returns (ms_per_step, log)."""
@@ -419,6 +444,8 @@ def main():
     if sres.reason <= 0:
         raise RuntimeError(f"Stokes solve did not converge: {sres}")
     WATCHDOG.tick("stokes")
+    halo_check = halo_overlap_selfcheck(P, world) if dist_on else None
+    WATCHDOG.tick("halo self-check")
     ms_per_step, log, w = timed_newton_steps(P, U, args.steps, args.warmup, world)
     value = n_dof_global / (ms_per_step * 1e-3) / 1e6
 
@@ -504,7 +531,7 @@ def main():
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "rccl_ranks": comm["rccl_ranks"],
-        "transport": comm["transport"], "steps": args.steps, "warmup": args.warmup,
+        "transport": comm["transport"], "halo_overlap_selfcheck": halo_check, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "precision_note": ("operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "

@@ -129,6 +129,15 @@ typedef struct {
     int    amg_retry_damping; /* 1 (default): a Krylov solve that ends in BREAKDOWN or NANORINF under SNS_PC_AMG is retried
                                once from the same guess with every level's block-Jacobi damping scaled by 0.7 (see
                                sns_krylov_solve); 0: the failed reason is reported and that is it, as PETSc does */
+    int    halo_overlap;    /* multi-GPU: 1 (default) = level-0 passes compute their interior rows on a second stream while the
+                               halo exchange is in flight and the boundary rows after it; 0 = exchange, then one full pass
+                               (same arithmetic per row, bitwise the same result).  The environment variable
+                               SNS_NO_OVERLAP=1 forces 0 */
+    int    amg_fused_post;  /* 1 (default): the coarse-grid correction and the first post-smoothing sweep of a level are ONE
+                               pass over M = A P (fine rows x coarse columns, 0.37x the blocks of A on a tet mesh's fine
+                               level; same low-precision format as the level matrix): z = (x1 + P xc) + w Dinv (r1 - M xc).
+                               The same linear operator as prolongation + sweep up to rounding.  Needs amg_f32_matrix != 0;
+                               0 = prolongation kernel + a full sweep over A */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
@@ -257,9 +266,10 @@ int sns_get_counters(sns_handle h, int64_t out[8]);
 int sns_comm_info(sns_handle h, int32_t out[4]);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
- * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot)     */
+ * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot,
+ *  4 fused correction + post-sweep on M = A P; 5..7 reserved)                  */
 int sns_time_kernels(sns_handle h, int on);
-int sns_get_kernel_times(sns_handle h, double ms_total[4], int64_t calls[4]);
+int sns_get_kernel_times(sns_handle h, double ms_total[8], int64_t calls[8]);
 /* raw kernel launchers for micro-benchmarks (bench.py roofline leg): run the
  * kernel `reps` times between two HIP events on the handle's stream and return
  * the average duration in ms.                                                  */

@@ -156,8 +156,8 @@ struct sns_ctx {
     std::vector<std::array<hipEvent_t, 2>> ev_pool;
     std::vector<int> ev_mode;
     size_t ev_used = 0;
-    double kt_ms[4] = {0, 0, 0, 0};
-    int64_t kt_calls[4] = {0, 0, 0, 0};
+    double kt_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // modes 0..3 = SpmvMode, 4 = fused post-sweep on M = A P
+    int64_t kt_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -365,7 +365,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         }
         launch_spmv<MODE>(h, L, rows, x, y, b, omega, dotw, sp);
     };
-    if (!dist || !h->bnd_flag || h->no_overlap) {
+    if (!dist || !h->bnd_flag || h->no_overlap || !h->opt.halo_overlap) {
         SNS_TRY(halo_exchange(h, xe));
         pass(Split());
         return SNS_OK;
@@ -471,6 +471,25 @@ int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg
         SNS_TRY(dev_alloc(&C.xg, 4 * (size_t)std::max(1, C.n)));
         HIP_TRY(hipMemset(C.xg, 0, 4 * (size_t)std::max(1, C.n) * sizeof(double)));
     }
+    return SNS_OK;
+}
+
+// symbolic part of M = A P of a level (fused first post-smoothing sweep, k_post_lp): pattern + gather lists -> device
+int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, const std::vector<int32_t>& agg_all) {
+    if (n_rows <= 0) return SNS_OK;
+    HostAP M;
+    try {
+        build_ap_pattern(fine, n_rows, agg_all, M);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return SNS_E_MESH;
+    }
+    L.ap_nnz = M.nnz;
+    SNS_TRY(dev_upload(&L.ap_rowptr, M.rowptr, h->stream));
+    SNS_TRY(dev_upload(&L.ap_colind, M.colind, h->stream));
+    SNS_TRY(dev_upload(&L.ap_slot_row, M.slot_row, h->stream));
+    SNS_TRY(dev_upload(&L.ap_ptr, M.ap_ptr, h->stream));
+    SNS_TRY(dev_upload(&L.ap_idx, M.ap_idx, h->stream));
     return SNS_OK;
 }
 
@@ -585,6 +604,7 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
             SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
             SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
             SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+            SNS_TRY(upload_ap(h, L, curp, n_own, A.agg));
         }
         SNS_TRY(append_level(h, A.coarse, nc, false));
         h->ghost_own.emplace_back();
@@ -691,6 +711,9 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
         SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
         SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+        // M = A P for the fused first post-smoothing sweep: every level of a serial hierarchy; in a partitioned one the fine
+        // level only (its single post-sweep is the exact global sweep; the distributed coarse levels smooth rank-locally)
+        if (!dist || l == 0) SNS_TRY(upload_ap(h, L, cur, n_owned, A.agg));
         h->levels.emplace_back();
         h->slot_row.push_back(nullptr);
         h->empty_c.push_back(nullptr);
@@ -974,6 +997,11 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     // deterministic start vector with all frequencies: x_i = 1 + (i*2654435761 mod 1024)/1024 via axpby on an iota is
     // overkill; use b of the last solve if any, else the diagonal-inverse row sums: simplest robust choice = all ones
     if (rows > 0) hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, x);
+    double* zero = nullptr;
+    if (lp_format(h, L) != 0) {
+        SNS_TRY(get_vec(h, 13, &zero));                  // level sizes never exceed the fine level
+        if (nd > 0) HIP_TRY(hipMemsetAsync(zero, 0, nd * sizeof(double), h->stream));
+    }
     double lam = 0.0;
     const int iters = 12;
     // distributed levels whose sweeps see exchanged ghost values are damped for the GLOBAL operator; purely
@@ -981,7 +1009,10 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     const bool glob = uses_ghosts_in_sweeps(h, l, L);
     for (int it = 0; it < iters; ++it) {
         if (glob) SNS_TRY(exchange_level(h, l, x));
-        launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
+        // the spectrum of the matrix the sweeps actually read: with a low-precision copy y = 0 - A~ x (the sign does not
+        // matter to ||Dinv A x||), half the bytes of the fp64 pass
+        if (lp_format(h, L) != 0 && zero) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, x, y, zero, 0.0);
+        else launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
         if (rows > 0) {
             hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
             hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, z, h->partial);   // (x.z, z.z)
@@ -1018,7 +1049,7 @@ int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
     // keep x0 intact (it seeds later trials): first sweep x0 -> xa, then ping-pong xa <-> xb
     const bool glob = uses_ghosts_in_sweeps(h, l, L);
     if (glob) SNS_TRY(exchange_level(h, l, x0));
-    launch_spmv<SPMV_JACOBI>(h, L, rows, x0, xa, zero, omega, nullptr);
+    launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x0, xa, zero, omega);
     double* cur = xa;
     double* oth = xb;
     const int sweeps = 6;
@@ -1029,7 +1060,7 @@ int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
             else reduce_local(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2));
         }
         if (glob) SNS_TRY(exchange_level(h, l, cur));
-        launch_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, zero, omega, nullptr);
+        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, zero, omega);
         std::swap(cur, oth);
     }
     double v[4];
@@ -1112,6 +1143,27 @@ int pc_setup(sns_ctx* h) {
             }
             if (h->opt.monitor) std::printf("    AMG level %d: n %d |lambda|max(Dinv A) %.4f omega %.4f\n", l, rows, lam, L.omega);
         }
+        if (l + 1 < nl && L.ap_rowptr && h->opt.amg_fused_post && h->opt.pc_type == SNS_PC_AMG && lp_format(h, L) != 0 &&
+            rows > 0) {
+            // numeric part of M = A P in the level's low-precision format
+            if (!L.ap_vals) SNS_TRY(dev_alloc(&L.ap_vals, (size_t)L.ap_nnz * 16));
+            hipLaunchKernelGGL(k_ap_sum, dim3((unsigned)((L.ap_nnz * 8 + 255) / 256)), dim3(256), 0, h->stream, L.ap_nnz,
+                               L.ap_ptr, L.ap_idx, L.vals, L.ap_slot_row, L.ap_colind, L.agg, L.free_mask, L.ap_vals);
+            if (lp_format(h, L) == 2) {
+                if (!L.ap_vals16) {
+                    uint2* v16 = nullptr;
+                    SNS_TRY(dev_alloc(&v16, (size_t)L.ap_nnz * 4));
+                    L.ap_vals16 = v16;
+                    SNS_TRY(dev_alloc(&L.ap_scale16, (size_t)4 * std::max(1, L.n)));
+                }
+                hipLaunchKernelGGL(k_cvt_h16, dim3((unsigned)((4 * (int64_t)rows + 255) / 256)), dim3(256), 0, h->stream, rows,
+                                   L.ap_rowptr, L.ap_vals, (uint2*)L.ap_vals16, L.ap_scale16);
+            } else {
+                if (!L.ap_vals32) SNS_TRY(dev_alloc(&L.ap_vals32, (size_t)L.ap_nnz * 16));
+                hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.ap_nnz * 16)), dim3(256), 0, h->stream, L.ap_nnz * 16, L.ap_vals,
+                                   L.ap_vals32);
+            }
+        }
         if (l + 1 < nl) {
             Level& C = h->levels[l + 1];
             const int64_t nth = C.nnzb * 8;
@@ -1180,6 +1232,7 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_nu_l2);
     sig.push_back(h->opt.amg_nu_l1_pre); sig.push_back(h->opt.amg_nu_l1_post);
     sig.push_back(h->opt.amg_f32_matrix);
+    sig.push_back(h->opt.amg_fused_post);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
         if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
@@ -1338,9 +1391,54 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
                            C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
-    if (rows > 0) hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     int s_first = 0;
-    if (px && l == 0 && nu == 1) {
+    // Fused coarse-grid correction + first post-smoothing sweep (k_post_lp): z = (cur + P xc) + om Dinv (r - M xc) with
+    // M = A P and r the residual restricted above -- the sweep reads M (0.37x the blocks of A on the fine level) instead
+    // of A and the prolongation kernel disappears.  Serial levels always; a distributed fine level when its single
+    // post-sweep is the exact global one (px): the ghost aggregates' corrections arrive by ONE level-(l+1) exchange
+    // instead of the level-l halo of the corrected iterate.
+    const int fmt_l = lp_format(h, L);
+    const bool have_m = h->opt.amg_fused_post && L.ap_rowptr && fmt_l != 0 && L.dinv32 &&
+                        (fmt_l == 2 ? L.ap_vals16 != nullptr : L.ap_vals32 != nullptr) && nu_post >= 1 && !sx;
+    const bool fused_post = have_m && (!L.xg || (l == 0 && px && nu == 1));
+    if (fused_post) {
+        const double* xc = C.x;
+        if (L.xg) {                                    // distributed fine level: xc incl. the neighbours' aggregates
+            if (C.n_owned > 0)
+                HIP_TRY(hipMemcpyAsync(C.xg, C.x, 4 * (size_t)C.n_owned * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            SNS_TRY(exchange_level(h, l + 1, C.xg));
+            xc = C.xg;
+        }
+        if (rows > 0) {
+            const int grid = (rows + 63) / 64;
+            const bool fine = (l == 0);
+            if (fine) time_begin(h, 4);
+            if (fmt_l == 2) {
+                if (fine)
+                    hipLaunchKernelGGL((k_post_lp<2, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth);
+                else
+                    hipLaunchKernelGGL((k_post_lp<2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth);
+            } else {
+                if (fine)
+                    hipLaunchKernelGGL((k_post_lp<1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
+                                       L.free_mask, oth);
+                else
+                    hipLaunchKernelGGL((k_post_lp<1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
+                                       L.free_mask, oth);
+            }
+            if (fine) time_end(h);
+        }
+        std::swap(cur, oth);
+        s_first = 1;
+    } else if (rows > 0) {
+        hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
+    }
+    if (fused_post) {
+    } else if (px && l == 0 && nu == 1) {
         // the single post-smoothing sweep of the fine level with the neighbours' corrected iterate: halo of `cur`
         // overlapped with the interior rows of the sweep
         SNS_TRY(exchange_and_spmv<SPMV_JACOBI>(h, cur, cur, oth, b, om, nullptr, true));
@@ -1855,6 +1953,8 @@ void sns_default_options(sns_options* o) {
     o->amg_nu_l1_pre = 0;
     o->amg_nu_l1_post = 0;
     o->amg_retry_damping = 1;
+    o->halo_overlap = 1;
+    o->amg_fused_post = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -2031,6 +2131,7 @@ int sns_destroy(sns_handle h) {
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_slot_row); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_vals); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);
@@ -2067,7 +2168,8 @@ int sns_set_stream(sns_handle h, void* s) {
 }
 int sns_set_options(sns_handle h, const sns_options* o) {
     if (!h || !o) return SNS_E_ARG;
-    const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix);
+    const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix) ||
+                            (o->amg_fused_post != h->opt.amg_fused_post);
     const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
     const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows) ||
                                         (o->amg_post_exchange != h->opt.amg_post_exchange);
@@ -2432,7 +2534,7 @@ int sns_reset_timings(sns_handle h) {
     if (!h) return SNS_E_ARG;
     h->tm = sns_timings{};
     h->ctr_retries = 0;
-    for (int i = 0; i < 4; ++i) { h->kt_ms[i] = 0; h->kt_calls[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->kt_ms[i] = 0; h->kt_calls[i] = 0; }
     return SNS_OK;
 }
 int sns_time_kernels(sns_handle h, int on) {
@@ -2440,9 +2542,9 @@ int sns_time_kernels(sns_handle h, int on) {
     h->time_kernels = on != 0;
     return SNS_OK;
 }
-int sns_get_kernel_times(sns_handle h, double ms_total[4], int64_t calls[4]) {
+int sns_get_kernel_times(sns_handle h, double ms_total[8], int64_t calls[8]) {
     if (!h || !ms_total || !calls) return SNS_E_ARG;
-    for (int i = 0; i < 4; ++i) { ms_total[i] = h->kt_ms[i]; calls[i] = h->kt_calls[i]; }
+    for (int i = 0; i < 8; ++i) { ms_total[i] = h->kt_ms[i]; calls[i] = h->kt_calls[i]; }
     return SNS_OK;
 }
 

@@ -225,6 +225,80 @@ void build_coarse_from_agg(const HostPattern& F, int32_t n_owned_fine, const std
     }
 }
 
+// Pattern of M = A P (fine rows x coarse columns) for the fused post-smoothing sweep (k_post_lp): row i holds one
+// block per aggregate its columns fall into; ap_ptr / ap_idx list, per M slot, the fine slots summed into it (fine-slot
+// order: deterministic).  Columns whose node takes no part in the transfer (agg < 0) are dropped.
+void build_ap_pattern(const HostPattern& F, int32_t n_rows, const std::vector<int32_t>& agg_all, HostAP& M) {
+    M.n = n_rows;
+    M.rowptr.assign((size_t)n_rows + 1, 0);
+    std::vector<int32_t> cnt((size_t)std::max(1, n_rows), 0);
+#pragma omp parallel
+    {
+        std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n_rows; ++i) {
+            tmp.clear();
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t J = agg_all[F.colind[k]];
+                if (J >= 0) tmp.push_back(J);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            cnt[i] = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+        }
+    }
+    int64_t nnz = 0;
+    for (int32_t i = 0; i < n_rows; ++i) nnz += cnt[i];
+    if (nnz > (int64_t)INT32_MAX) throw std::runtime_error("A*P pattern exceeds int32 slots");
+    for (int32_t i = 0; i < n_rows; ++i) M.rowptr[i + 1] = M.rowptr[i] + cnt[i];
+    M.nnz = nnz;
+    M.colind.resize((size_t)nnz);
+    M.slot_row.resize((size_t)nnz);
+    M.ap_ptr.assign((size_t)nnz + 1, 0);
+    M.ap_idx.resize((size_t)(n_rows > 0 ? F.rowptr[n_rows] : 0));
+#pragma omp parallel
+    {
+        std::vector<int32_t> tmp, fill;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n_rows; ++i) {
+            tmp.clear();
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t J = agg_all[F.colind[k]];
+                if (J >= 0) tmp.push_back(J);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            const int32_t m0 = M.rowptr[i];
+            std::copy(tmp.begin(), tmp.end(), M.colind.begin() + m0);
+            for (size_t q = 0; q < tmp.size(); ++q) M.slot_row[(size_t)m0 + q] = i;
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t J = agg_all[F.colind[k]];
+                if (J < 0) continue;
+                const int32_t q = (int32_t)(std::lower_bound(tmp.begin(), tmp.end(), J) - tmp.begin());
+                M.ap_ptr[(size_t)m0 + q + 1]++;
+            }
+        }
+    }
+    // ap_ptr currently holds per-slot counts (shifted by one): prefix sum, then fill in fine-slot order
+    for (int64_t s = 0; s < nnz; ++s) M.ap_ptr[s + 1] += M.ap_ptr[s];
+    M.ap_idx.resize((size_t)M.ap_ptr[nnz]);
+#pragma omp parallel
+    {
+        std::vector<int32_t> fill;
+#pragma omp for schedule(dynamic, 1024)
+        for (int32_t i = 0; i < n_rows; ++i) {
+            const int32_t m0 = M.rowptr[i], len = M.rowptr[i + 1] - m0;
+            fill.assign((size_t)len, 0);
+            const int32_t* cb = M.colind.data() + m0;
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t J = agg_all[F.colind[k]];
+                if (J < 0) continue;
+                const int32_t q = (int32_t)(std::lower_bound(cb, cb + len, J) - cb);
+                M.ap_idx[(size_t)(M.ap_ptr[(size_t)m0 + q] + fill[q]++)] = k;
+            }
+        }
+    }
+}
+
 void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_agg, HostAggregation& A) {
     std::vector<int32_t> agg;
     int32_t nc = 0;

@@ -35,6 +35,15 @@ struct HostAggregation {
     std::vector<int32_t> r_idx;
 };
 
+struct HostAP {                          // pattern of M = A P (fine rows x coarse columns) + its gather lists
+    int32_t n = 0;
+    int64_t nnz = 0;
+    std::vector<int32_t> rowptr, colind; // per fine row: the aggregates its columns fall into (sorted)
+    std::vector<int32_t> slot_row;       // fine row of each M slot
+    std::vector<int32_t> ap_ptr, ap_idx; // M slot -> fine slots summed into it
+};
+void build_ap_pattern(const HostPattern& F, int32_t n_rows, const std::vector<int32_t>& agg_all, HostAP& M);
+
 void build_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets, HostPattern& P,
                    HostAssemblyMaps& M, int npe = 4);
 void build_aggregation(const HostPattern& fine, int max_agg, HostAggregation& A);
@@ -62,6 +71,14 @@ struct Level {
     int64_t* r_ptr = nullptr;
     int32_t* r_idx = nullptr;
     uint8_t* free_mask = nullptr;        // 4*n: 1 where dof takes part in transfer (level 0: !bc), else all 1
+    // M = A P of this level for the fused first post-smoothing sweep (k_post_lp): pattern + gather lists (symbolic, once),
+    // fp64 values per numeric setup and their low-precision copy in the level's format
+    int64_t ap_nnz = 0;
+    int32_t *ap_rowptr = nullptr, *ap_colind = nullptr, *ap_slot_row = nullptr, *ap_ptr = nullptr, *ap_idx = nullptr;
+    double* ap_vals = nullptr;
+    float* ap_vals32 = nullptr;
+    void* ap_vals16 = nullptr;
+    float* ap_scale16 = nullptr;
     // work vectors (4*n doubles)
     double *x = nullptr, *b = nullptr, *r = nullptr;
     double* xg = nullptr;                // distributed runs: copy of the iterate whose ghost tail is exchanged

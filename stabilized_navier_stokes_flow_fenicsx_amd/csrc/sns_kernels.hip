@@ -1667,6 +1667,178 @@ SNS_INST_LP_FMT(2)
 SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, 2, 0) SNS_INST_LP(SPMV_JACOBI, 1, 0, 2, 0)      // in-solver A/B of the stepped loop
 #endif
 
+// k_post_lp: the FIRST post-smoothing sweep of a V-cycle level fused with the coarse-grid correction (round 3).
+// With x2 = x1 + P xc the sweep z = x2 + w Dinv (b - A x2) equals
+//     z = (x1 + P xc) + w Dinv (r1 - M xc),   r1 = b - A x1 (the residual the level restricts anyway),  M = A P,
+// and M -- fine rows x COARSE columns, the blocks of a row summed per aggregate (k_ap_sum) -- has 0.37x the blocks of A on
+// a tet mesh's fine level (15 neighbours fall into <= 8 aggregates).  So the sweep reads M instead of A and gathers from
+// the small coarse vector, and the prolongation kernel disappears (x1 + P xc is the row's own epilogue operand).  Same
+// linear operator as before up to rounding; M is held in the same low-precision format as the level matrix (fp16 with
+// row scales, pair-interleaved, or fp32).  4 lanes per block row like k_spmv_lp; the first 8 blocks of a row (all of it
+// on the fine level) are requested up-front.
+template <int FMT, int FINE>
+__global__ __launch_bounds__(256) void k_post_lp(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
+                                                 const float* __restrict__ scale, const double* __restrict__ xc,
+                                                 const double* __restrict__ x_pre, const double* __restrict__ res1,
+                                                 const float* __restrict__ dinv, double omega,
+                                                 const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
+                                                 double* __restrict__ y) {
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 3;
+    const int32_t row = (blk * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool live = row < n_rows;
+    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
+    float4 pre_d = make_float4(0.f, 0.f, 0.f, 0.f);
+    int32_t I = -1;
+    if (live) {
+        I = agg[row];
+        if (FMT == 2) sc = (double)scale[4 * (int64_t)row + r];
+        pre_b = res1[4 * (int64_t)row + r];
+        pre_x = x_pre[4 * (int64_t)row + r];
+        pre_d = *reinterpret_cast<const float4*>(dinv + 16 * (int64_t)row + 4 * r);
+        if (I >= 0 && (!free_mask || free_mask[4 * (int64_t)row + r])) pre_x += xc[4 * (int64_t)I + r];   // (x1 + P xc)_row
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);
+    const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);
+    int32_t k = s;
+    if constexpr (FMT == 2) {
+        constexpr int NS = 2;
+        const int32_t cnt = e - s;
+        const int32_t np = cnt >> 1;
+        int32_t c[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) c[t] = (4 * t + r < cnt) ? colind[s + 4 * t + r] : 0;      // masked: coarse node 0 (in bounds)
+        uint4 P[2 * NS];
+#pragma unroll
+        for (int q = 0; q < 2 * NS; ++q) {
+            P[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < np) P[q] = v16[4 * q];
+            else if (q == np && (cnt & 1)) {
+                const uint2 o = reinterpret_cast<const uint2*>(vals_v)[(int64_t)(e - 1) * 4 + r];
+                P[q].x = o.x; P[q].y = o.y;
+            }
+        }
+        double2 xa[NS], xb[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)c[t]);
+            xa[t] = xp[0]; xb[t] = xp[1];
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&P[2 * t]), h1 = *reinterpret_cast<const f16x8_t*>(&P[2 * t + 1]);
+            acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa[t]), quad_bcast2<0>(xb[t]));
+            acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa[t]), quad_bcast2<1>(xb[t]));
+            acc0 += lp_dot(h1.lo, quad_bcast2<2>(xa[t]), quad_bcast2<2>(xb[t]));
+            acc1 += lp_dot(h1.hi, quad_bcast2<3>(xa[t]), quad_bcast2<3>(xb[t]));
+        }
+        k = (cnt > 4 * NS) ? s + 4 * NS : e;
+        v16 += 8 * NS;
+    }
+    for (; k + 3 < e; k += 4) {                                   // longer rows (coarse levels, unstructured meshes)
+        const int32_t cme = colind[k + r];
+        const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];
+        if (FMT == 1) {
+            const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
+            acc0 += lp_dot(a0, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            acc1 += lp_dot(a1, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            acc0 += lp_dot(a2, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            acc1 += lp_dot(a3, quad_bcast2<3>(xa), quad_bcast2<3>(xb));
+            v32 += 16;
+        } else {
+            const uint4 p0 = v16[0], p1 = v16[4];
+            const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0), h1 = *reinterpret_cast<const f16x8_t*>(&p1);
+            acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            acc0 += lp_dot(h1.lo, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            acc1 += lp_dot(h1.hi, quad_bcast2<3>(xa), quad_bcast2<3>(xb));
+            v16 += 8;
+        }
+    }
+    if (k < e) {                                                  // 1..3 blocks left; quad-uniform
+        const int32_t left = e - k;
+        const int32_t cme = colind[k + (r < left ? r : 0)];
+        const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];
+        if (FMT == 1) {
+            acc0 += lp_dot(v32[0], quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+            if (left > 1) acc1 += lp_dot(v32[4], quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            if (left > 2) acc0 += lp_dot(v32[8], quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+        } else {
+            if (left > 1) {
+                const uint4 p0 = v16[0];
+                const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0);
+                acc0 += lp_dot(h0.lo, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+                acc1 += lp_dot(h0.hi, quad_bcast2<1>(xa), quad_bcast2<1>(xb));
+            }
+            if (left & 1) {
+                const uint2 q = reinterpret_cast<const uint2*>(vals_v)[(int64_t)(e - 1) * 4 + r];
+                const f16x4_t hq = *reinterpret_cast<const f16x4_t*>(&q);
+                if (left == 1) acc0 += lp_dot(hq, quad_bcast2<0>(xa), quad_bcast2<0>(xb));
+                else acc0 += lp_dot(hq, quad_bcast2<2>(xa), quad_bcast2<2>(xb));
+            }
+        }
+    }
+    const double acc = sc * (acc0 + acc1);                        // (M xc)[4*row + r]
+    const double rr = live ? (pre_b - acc) : 0.0;
+    const double r0 = quad_bcast<0>(rr), r1 = quad_bcast<1>(rr), r2 = quad_bcast<2>(rr), r3 = quad_bcast<3>(rr);
+    if (live)
+        y[4 * (int64_t)row + r] = pre_x + omega * ((double)pre_d.x * r0 + (double)pre_d.y * r1 + (double)pre_d.z * r2 +
+                                                    (double)pre_d.w * r3);
+}
+#define SNS_INST_POST(T, F)                                                                                        \
+    template __global__ void k_post_lp<T, F>(int32_t, const int32_t*, const int32_t*, const void*, const float*,   \
+                                             const double*, const double*, const double*, const float*, double,   \
+                                             const int32_t*, const uint8_t*, double*);
+SNS_INST_POST(1, 0) SNS_INST_POST(1, 1) SNS_INST_POST(2, 0) SNS_INST_POST(2, 1)
+
+// M = A P for the fused post-smoothing sweep: M slot (i, J) <- sum of the fine blocks (i, j), j in aggregate J (gather
+// list ap_ptr / ap_idx, fixed order).  Dofs excluded from the transfer (level 0: Dirichlet dofs) have zero columns in A
+// except the unit diagonal (:74), so the only thing to take out is that 1.0 where the row's own node is in J.
+// 8 lanes per slot, one double2 each (as k_galerkin).
+__global__ __launch_bounds__(256) void k_ap_sum(int64_t nnz_m, const int32_t* __restrict__ ap_ptr,
+                                                const int32_t* __restrict__ ap_idx, const double* __restrict__ vals_f,
+                                                const int32_t* __restrict__ slot_row_m,
+                                                const int32_t* __restrict__ colind_m, const int32_t* __restrict__ agg,
+                                                const uint8_t* __restrict__ free_mask, double* __restrict__ vals_m) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 3;
+    const int t = (int)(gid & 7);
+    if (s >= nnz_m) return;
+    double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+    const int32_t k1 = ap_ptr[s + 1];
+    int32_t k = ap_ptr[s];
+    for (; k + 1 < k1; k += 2) {
+        const int32_t f0 = ap_idx[k], f1 = ap_idx[k + 1];
+        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)f0 * 16)[t];
+        const double2 b = reinterpret_cast<const double2*>(vals_f + (int64_t)f1 * 16)[t];
+        v0.x += a.x; v0.y += a.y;
+        v1.x += b.x; v1.y += b.y;
+    }
+    if (k < k1) {
+        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)ap_idx[k] * 16)[t];
+        v0.x += a.x; v0.y += a.y;
+    }
+    double2 v = make_double2(v0.x + v1.x, v0.y + v1.y);
+    if (free_mask) {
+        const int32_t i = slot_row_m[s];
+        if (agg[i] == colind_m[s]) {
+            const int c = t >> 1;                          // lane t holds entries (c, 2*(t&1)) and (c, 2*(t&1)+1)
+            if (!free_mask[4 * (int64_t)i + c] && (t & 1) == (c >> 1)) {
+                if (c & 1) v.y -= 1.0;
+                else v.x -= 1.0;
+            }
+        }
+    }
+    reinterpret_cast<double2*>(vals_m + s * 16)[t] = v;
+}
+
 // fp16 copy of a BSR4 matrix with one scale per dof row, in the pair-interleaved layout k_spmv_lp<FMT 2> reads:
 // 4 lanes per block row, lane r owns dof row 4*row + r.  Block j of a row (j = k - rowptr[row]) that has a partner
 // (j ^ 1 within the row) lands in pair j >> 1, half j & 1; an odd last block keeps the plain position.

@@ -305,11 +305,11 @@ class FlowProblem:
 
     def kernel_times(self):
         """{mode: (total_ms, calls)} of the level-0 k_spmv family since reset_timings()."""
-        ms = (C.c_double * 4)()
-        calls = (C.c_int64 * 4)()
+        ms = (C.c_double * 8)()
+        calls = (C.c_int64 * 8)()
         check(self.lib.sns_get_kernel_times(self.h, ms, calls))
-        names = ("ax", "b_minus_ax", "jacobi", "ax_dot")
-        return {names[i]: (ms[i], calls[i]) for i in range(4)}
+        names = ("ax", "b_minus_ax", "jacobi", "ax_dot", "post_m")
+        return {names[i]: (ms[i], calls[i]) for i in range(5)}
 
     def timings(self) -> SnsTimings:
         t = SnsTimings()

@@ -31,6 +31,23 @@ int main() {
         aggregate_nodes(cur, nown, 8, agg, nc);
         HostAggregation A; build_coarse_from_agg(cur, nown, agg, nc, nc, A);
         std::printf("level %d: %d -> %d nodes, coarse nnzb %ld, r_idx %zu\n", l, nown, nc, (long)A.coarse.nnzb, A.r_idx.size());
+        // M = A P pattern of the fused post-smoothing sweep: every fine slot lands in exactly one M slot of its row,
+        // the M slot's column is the aggregate of the fine slot's column, columns sorted and unique per row
+        HostAP M2; build_ap_pattern(cur, nown, A.agg, M2);
+        if (M2.ap_ptr.back() != cur.rowptr[nown] || (int64_t)M2.colind.size() != M2.nnz) { std::printf("ERROR ap sizes\n"); return 1; }
+        std::vector<char> seen((size_t)cur.rowptr[nown], 0);
+        for (int32_t i = 0; i < nown; ++i)
+            for (int32_t s = M2.rowptr[i]; s < M2.rowptr[i + 1]; ++s) {
+                if (s > M2.rowptr[i] && M2.colind[s] <= M2.colind[s - 1]) { std::printf("ERROR ap order\n"); return 1; }
+                if (M2.slot_row[s] != i) { std::printf("ERROR ap slot_row\n"); return 1; }
+                for (int32_t q = M2.ap_ptr[s]; q < M2.ap_ptr[s + 1]; ++q) {
+                    const int32_t k = M2.ap_idx[q];
+                    if (k < cur.rowptr[i] || k >= cur.rowptr[i + 1] || A.agg[cur.colind[k]] != M2.colind[s] || seen[k]++) {
+                        std::printf("ERROR ap gather list\n"); return 1;
+                    }
+                }
+            }
+        std::printf("level %d: A*P pattern %ld slots (%.2f of the level's blocks)\n", l, (long)M2.nnz, (double)M2.nnz / cur.rowptr[nown]);
         cur = A.coarse; nown = nc;
     }
     // partial-active aggregation (distributed level 0)
