@@ -119,16 +119,20 @@ typedef struct {
                                a0/(4 nu), a0 = 1/3: LidDrivenNavierStokesFlow.py:98-100) */
     int    amg_fine_cycle;  /* shape of the AMG cycle on the fine level (single GPU): 0 = V(1,1) (default),
                                1 = V(0,1) (no pre-smoothing), 2 = V(1,0) (no post-smoothing) */
-    int    amg_nu_l1_pre;   /* sweeps BEFORE the coarse-grid correction on level 1 (0 = amg_nu_coarse, the default); the
-                               first one is omega D^-1 b from the zero guess, no matrix pass */
-    int    amg_nu_l1_post;  /* sweeps AFTER the coarse-grid correction on level 1 (0 = amg_nu_coarse, the default).
-                               Measured: 1 + 6 needs the iterations of 4 + 4 on the 10 M-tet duct at
-                               Re 200 with one level-1 matrix pass less per cycle (-3 % per Newton iteration), is neutral on
-                               the other workloads, costs 10 % more Stokes iterations and 8-11 % more iterations in
-                               partitioned runs (rank-local post-smoothing) -- hence off by default */
+    int    amg_nu_l1_pre;   /* sweeps BEFORE the coarse-grid correction on level 1; the first one is omega D^-1 b from the zero
+                               guess, no matrix pass.  0 (default) = automatic, see amg_nu_l1_post */
+    int    amg_nu_l1_post;  /* sweeps AFTER the coarse-grid correction on level 1.  Both 0 (default) = automatic: a single-GPU
+                               handle runs 1 + (amg_nu_coarse + 2) = 1 + 6 -- post-smoothing is the more valuable half under a
+                               piecewise-constant prolongation: the iterations of 4 + 4 with one level-1 matrix pass less
+                               (-3 % per Newton iteration on the 10 M-tet duct, neutral on configs 3 / 4, Stokes +1 iteration);
+                               a partitioned handle runs amg_nu_coarse + amg_nu_coarse (its post-sweeps are rank-local and
+                               1 + 6 costs 8-11 % more iterations there).  Set both (e.g. 4 and 4) to fix the counts */
     int    amg_retry_damping; /* 1 (default): a Krylov solve that ends in BREAKDOWN or NANORINF under SNS_PC_AMG is retried
                                once from the same guess with every level's block-Jacobi damping scaled by 0.7 (see
                                sns_krylov_solve); 0: the failed reason is reported and that is it, as PETSc does */
+    int    amg_retry_stall_its; /* with amg_retry_damping: the first BiCGStab attempt also counts as broken down when its best
+                               residual norm has not improved by 10 % for this many iterations (200; 0 = breakdown / NaN only).
+                               An over-relaxed smoother makes BiCGStab stagnate far more often than break down outright */
     int    halo_overlap;    /* multi-GPU: 1 (default) = level-0 passes compute their interior rows on a second stream while the
                                halo exchange is in flight and the boundary rows after it; 0 = exchange, then one full pass
                                (same arithmetic per row, bitwise the same result).  The environment variable
@@ -219,7 +223,8 @@ int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
 /* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
  * guess on entry.  rnorm = 2-norm of the TRUE residual b - A x at exit.  With
  * amg_retry_damping (default on) a solve that ends in DIVERGED_BREAKDOWN or
- * DIVERGED_NANORINF under SNS_PC_AMG is retried ONCE from the same guess with every
+ * DIVERGED_NANORINF (or, BiCGStab, stagnates for amg_retry_stall_its iterations: reported
+ * as a breakdown) under SNS_PC_AMG is retried ONCE from the same guess with every
  * level's block-Jacobi damping scaled by 0.7; the factor stays until the next
  * sns_set_options.  *its then counts both attempts (<= 2 ksp_max_it), *reason is the
  * last attempt's, the first attempt's is out[6] of sns_get_counters.  Running out of
@@ -258,7 +263,8 @@ int sns_get_timings(sns_handle h, sns_timings* t);
 /* debug counters of the LAST Krylov solve: out[0] = host<->device synchronisations (stream / event waits),
  * out[1] = all-reduces, out[2] = neighbour (halo) exchanges; out[3] = Krylov iterations since reset_timings,
  * out[4] = damping retries since reset_timings, out[5] = current damping factor x 1e6 (1000000 = no retry so far),
- * out[6] = reason of the first attempt of the last solve if it was retried (else 0), out[7] = reserved (0) */
+ * out[6] = reason of the first attempt of the last solve if it was retried (else 0), out[7] = blocks of the fine level's
+ * M = A P (fused post-smoothing sweep; 0 until the hierarchy exists) */
 int sns_get_counters(sns_handle h, int64_t out[8]);
 /* communicator of the handle: out[0] = transport (0 none, 1 RCCL, 2 in-process team), out[1] = this rank,
  * out[2] = ranks the handle was attached with, out[3] = ranks RCCL itself reports (ncclCommCount; 0 without RCCL):

@@ -2,7 +2,7 @@
 usage: trim_pmc.py <in counter_collection.csv> <out csv>"""
 import csv, re, sys
 keep = ("k_fused_", "k_element<", "k_gather_", "k_residual_tet")
-fine = re.compile(r"k_spmv(_lp)?<\d+, 1, ")            # second template argument FINE == 1
+fine = re.compile(r"k_spmv(_lp)?<\d+, 1, |k_post_lp<\d+, 1>")     # FINE == 1 instantiations (level 0)
 with open(sys.argv[1]) as fi, open(sys.argv[2], "w", newline="") as fo:
     r = csv.DictReader(fi)
     w = csv.DictWriter(fo, fieldnames=r.fieldnames)

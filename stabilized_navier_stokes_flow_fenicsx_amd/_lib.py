@@ -36,6 +36,7 @@ class SnsOptions(C.Structure):
         ("amg_nu_l1_pre", C.c_int),
         ("amg_nu_l1_post", C.c_int),
         ("amg_retry_damping", C.c_int),
+        ("amg_retry_stall_its", C.c_int),
         ("halo_overlap", C.c_int),
         ("amg_fused_post", C.c_int),
     ]

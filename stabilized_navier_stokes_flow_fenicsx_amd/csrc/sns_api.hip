@@ -1342,6 +1342,15 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     {
         const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;
         if (ll == 1) {
+            // automatic (both options 0): a single-GPU handle runs 1 + (nu + 2) sweeps -- post-smoothing is the more valuable
+            // half under a piecewise-constant prolongation, 1 + 6 needs the iterations of 4 + 4 with one level-1 pass less
+            // (-3 % per Newton step on the 10 M-tet duct, neutral elsewhere); a partitioned handle keeps nu + nu, its
+            // post-sweeps being rank-local (1 + 6 costs 8-11 % more iterations there)
+            const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
+            if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
+                nu_pre = 1;
+                nu_post = nu + 2;
+            }
             if (h->opt.amg_nu_l1_pre > 0) nu_pre = h->opt.amg_nu_l1_pre;
             if (h->opt.amg_nu_l1_post > 0) nu_post = h->opt.amg_nu_l1_post;
         }
@@ -1542,7 +1551,7 @@ int dot(sns_ctx* h, const double* x, const double* y, double* out) {
 // FIRST HALF of the next iteration (p, M p, A M p, <rhat, v>, alpha: none of it touches x or r) are enqueued
 // behind it, and only then does the host wait for the copy's event -- the GPU never idles on the stopping test.
 // A converged claim is confirmed by the explicitly computed ||r|| before the loop is left.
-int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out) {
+int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out, double* rnorm_out, int stall_window) {
     const sns_options& o = h->opt;
     const int64_t nd = nred_of(h);
     const int g = vec_grid(nd);
@@ -1587,6 +1596,8 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             return SNS_OK;
         };
         SNS_TRY(first_half());
+        double best_rn = rn;
+        int best_it = 0;
         for (its = 1;; ++its) {
             hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
             SNS_TRY(pc_apply(h, s, sh));
@@ -1619,6 +1630,11 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             }
             if (flags & 2) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
             if (its >= o.ksp_max_it) { reason = SNS_KSP_DIVERGED_ITS; break; }
+            // stagnation watch of the damping-retry feature (stall_window > 0 only on an attempt that can still be retried):
+            // BiCGStab under an over-relaxed smoother often does not break down outright but wanders without ever
+            // improving on its best residual; after stall_window iterations without a 10 % improvement the attempt is over
+            if (rn < 0.9 * best_rn) { best_rn = rn; best_it = its; }
+            if (stall_window > 0 && its - best_it >= stall_window) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
             if (flags & 4) { reason = SNS_KSP_DIVERGED_BREAKDOWN; ++its; break; }   // rho == 0 stops the NEXT iteration
         }
         // the stopping test runs on the RECURRENCE residual (as PETSc's bcgs does); what is reported is the true one,
@@ -1855,7 +1871,9 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     // operator, and at cell Reynolds numbers of 5-10 a slightly over-relaxed smoother is what breaks BiCGStab down
     // (measured: jittered 648 k-tet duct, Re 200: auto damping fails after 218 iterations, 0.7 x converges).  A solve
     // that merely runs out of iterations (DIVERGED_ITS) is NOT retried: like PETSc, the reason is reported and that is
-    // it.  The smaller damping is kept for the later Jacobians of the handle until sns_set_options is called; the
+    // it.  Because BiCGStab under an over-relaxed smoother more often STAGNATES than breaks down (the same 648 k-tet case,
+    // round 3: it wanders between 0.2 and 70 x ||b|| for as long as it is allowed to), the first attempt also ends -- as a
+    // breakdown -- when its best residual has not improved by 10 % for amg_retry_stall_its (200) iterations.  The smaller damping is kept for the later Jacobians of the handle until sns_set_options is called; the
     // retry count and the current factor are visible through sns_get_counters.  *its is the sum over both attempts
     // (<= 2 ksp_max_it).  Not in the reference; converging solves never see it.
     const bool can_retry = h->opt.pc_type == SNS_PC_AMG && h->opt.amg_retry_damping != 0 && h->damping_backoff > 0.4;
@@ -1868,7 +1886,8 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
     h->last_first_reason = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
-        if (h->opt.ksp_type == SNS_KSP_BICGSTAB) rc = bicgstab(h, b, x, its, reason, rnorm);
+        if (h->opt.ksp_type == SNS_KSP_BICGSTAB)
+            rc = bicgstab(h, b, x, its, reason, rnorm, (can_retry && attempt == 0) ? h->opt.amg_retry_stall_its : 0);
         else if (h->opt.ksp_type == SNS_KSP_FGMRES) rc = fgmres(h, b, x, its, reason, rnorm);
         else if (h->opt.ksp_type == SNS_KSP_TFQMR) rc = tfqmr(h, b, x, its, reason, rnorm);
         else { set_error("bad ksp_type"); return SNS_E_ARG; }
@@ -1953,6 +1972,7 @@ void sns_default_options(sns_options* o) {
     o->amg_nu_l1_pre = 0;
     o->amg_nu_l1_post = 0;
     o->amg_retry_damping = 1;
+    o->amg_retry_stall_its = 200;
     o->halo_overlap = 1;
     o->amg_fused_post = 1;
 }
@@ -2505,7 +2525,7 @@ int sns_get_counters(sns_handle h, int64_t out[8]) {
     out[4] = h->ctr_retries;
     out[5] = (int64_t)std::llround(h->damping_backoff * 1e6);
     out[6] = h->last_first_reason;
-    out[7] = 0;
+    out[7] = h->levels[0].ap_nnz;
     return SNS_OK;
 }
 int sns_comm_info(sns_handle h, int32_t out[4]) {

@@ -321,7 +321,7 @@ class FlowProblem:
         c = (C.c_int64 * 8)()
         check(self.lib.sns_get_counters(self.h, c))
         return dict(host_syncs=c[0], allreduces=c[1], exchanges=c[2], ksp_its=c[3], damping_retries=c[4],
-                    damping_factor=c[5] * 1e-6, first_attempt_reason=c[6])
+                    damping_factor=c[5] * 1e-6, first_attempt_reason=c[6], ap_blocks=c[7])
 
     def comm_info(self):
         """Transport / rank / ranks of the handle's communicator; ``rccl_ranks`` is what ncclCommCount reports."""
