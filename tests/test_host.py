@@ -367,6 +367,34 @@ def test_host_symbolic_setup_under_sanitizers(tmp_path):
     assert "active aggregation" in run.stdout and "ERROR" not in run.stderr
 
 
+def test_delaunay_channel_mesh_geometry_and_tags():
+    """mesh.delaunay_channel_mesh (bench.py --config 4u; the unstructured stand-in for the reference's gmsh meshes,
+    image2gmsh3D.py:445-486): watertight 4 x 1 x 1 box, channel tag set with the inlet split by facet centroid, node
+    ids x-slowest (x-slabs stay contiguous id ranges), variable valence, no degenerate tets; both lattices."""
+    for lattice, qmin in (("bcc", 0.3), ("cubic", 1e-6)):
+        m = M.delaunay_channel_mesh(6, lattice=lattice, seed=1)
+        X4 = m.points[m.tets]
+        vol = np.abs(np.linalg.det(np.stack([X4[:, 1] - X4[:, 0], X4[:, 2] - X4[:, 0], X4[:, 3] - X4[:, 0]], axis=2))) / 6
+        assert abs(vol.sum() - 4.0) < 1e-9 and vol.min() > 0
+        e = np.stack([np.linalg.norm(X4[:, a] - X4[:, b], axis=1) for a in range(4) for b in range(a + 1, 4)], axis=1)
+        q = 6 * np.sqrt(2) * vol / np.sqrt((e ** 2).mean(axis=1)) ** 3                   # 1 for a regular tet
+        assert np.quantile(q, 0.01) > qmin
+        t = m.meta["tags"]
+        assert set(np.unique(m.facet_tags)) == {t["inlet_1"], t["inlet_2"], t["outlet"], t["wall"]}
+        fa = 0.5 * np.linalg.norm(np.cross(m.points[m.facets[:, 1]] - m.points[m.facets[:, 0]],
+                                           m.points[m.facets[:, 2]] - m.points[m.facets[:, 0]]), axis=1)
+        assert abs(fa[m.facet_tags == t["outlet"]].sum() - 1.0) < 1e-9
+        assert abs(fa[(m.facet_tags == t["inlet_1"]) | (m.facet_tags == t["inlet_2"])].sum() - 1.0) < 1e-9
+        assert abs(fa[m.facet_tags == t["wall"]].sum() - 16.0) < 1e-9
+        assert 0.1 < fa[m.facet_tags == t["inlet_1"]].sum() < 0.5                         # the centred 0.5 x 0.5 square, by centroid
+        x = m.points[:, 0]
+        assert np.all(np.diff(np.round(x / (0.5 / 6))) >= 0)                              # x-slowest node ids
+        deg = np.bincount(m.tets.ravel(), minlength=m.num_nodes)
+        assert deg.min() >= 1 and deg.max() > 2 * deg.min()
+        mask, g = B.channel_bcs(m, *B.two_stream_profiles(0.5)).flatten()
+        assert mask.reshape(-1, 4)[:, 3].sum() == len(m.facet_nodes(t["outlet"]))         # p = 0 on the outlet only
+
+
 def test_dfg_pillar_mesh_geometry():
     """Delaunay mesh of the DFG pillar channel (dfg_pillar_3D.geo): watertight, fluid volume and pillar surface
     area as the geometry says (the pillar is a polygonal prism: slightly larger volume, smaller area), tags and
