@@ -1585,8 +1585,8 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
         HIP_TRY(hipMemcpyAsync(rhat, r, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(v, 0, nd * sizeof(double), h->stream));
-        auto first_half = [&]() -> int {                  // p, ph = M p, v = A ph, alpha
-            hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, p);
+        auto first_half = [&](bool p_done) -> int {       // p, ph = M p, v = A ph, alpha
+            if (!p_done) hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, p);
             SNS_TRY(pc_apply(h, p, ph));
             const int32_t rows = h->n_owned;
             const int gs = (rows + 31) / 32;
@@ -1595,7 +1595,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
             return SNS_OK;
         };
-        SNS_TRY(first_half());
+        SNS_TRY(first_half(false));
         double best_rn = rn;
         int best_it = 0;
         for (its = 1;; ++its) {
@@ -1607,10 +1607,15 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             hipLaunchKernelGGL(k_bicg_omega, dim3(1), dim3(64), 0, h->stream, sc, red);
             HIP_TRY(hipMemcpyAsync(hpin, sc + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipEventRecord(h->ev_it, h->stream));
-            hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, x, r);
-            // speculative first half of the next iteration, enqueued BEFORE the host looks at this one's result
+            // speculative first half of the next iteration, enqueued BEFORE the host looks at this one's result; its p-update
+            // rides on the x / r update (k_bicg_xrp)
             const bool spec = its < o.ksp_max_it;
-            if (spec) SNS_TRY(first_half());
+            if (spec) {
+                hipLaunchKernelGGL(k_bicg_xrp, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p);
+                SNS_TRY(first_half(true));
+            } else {
+                hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, x, r);
+            }
             HIP_TRY(hipEventSynchronize(h->ev_it));
             ++h->ctr_host_syncs;
             const double rr = hpin[0];

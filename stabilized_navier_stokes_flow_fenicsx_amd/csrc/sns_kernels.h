@@ -81,6 +81,8 @@ __global__ void k_bicg_dots5(int64_t n, const double* s, const double* t, const 
 __global__ void k_bicg_omega(double* sc, const double* red);
 __global__ void k_bicg_xr(int64_t n, const double* sc, const double* ph, const double* sh, const double* s,
                           const double* t, double* x, double* r);
+__global__ void k_bicg_xrp(int64_t n, const double* sc, const double* ph, const double* sh, const double* s,
+                           const double* t, const double* v, double* x, double* r, double* p);
 __global__ void k_bicg_init(double* sc, const double* rr0);
 __global__ void k_multi_dot8(int64_t n, int nv, const double* V, int64_t ldv, const double* w, double* partial);
 __global__ void k_multi_axpy8(int64_t n, int nv, const double* V, int64_t ldv, const double* h, double sign,

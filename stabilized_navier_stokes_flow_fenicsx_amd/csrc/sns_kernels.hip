@@ -1676,8 +1676,10 @@ SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, 2, 0) SNS_INST_LP(SPMV_JACOBI, 1, 0, 2, 0)   
 // linear operator as before up to rounding; M is held in the same low-precision format as the level matrix (fp16 with
 // row scales, pair-interleaved, or fp32).  4 lanes per block row like k_spmv_lp; the first 8 blocks of a row (all of it
 // on the fine level) are requested up-front.
+// __launch_bounds__(256, 6): 80 instead of 103 VGPRs (fp16), 6 instead of 4 waves per SIMD, no spills -- unlike the full
+// sweeps this kernel gains from the occupancy (in-solver A/B at 10 M tets: 169 -> 147 us)
 template <int FMT, int FINE>
-__global__ __launch_bounds__(256) void k_post_lp(int32_t n_rows, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                                  const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
                                                  const float* __restrict__ scale, const double* __restrict__ xc,
                                                  const double* __restrict__ x_pre, const double* __restrict__ res1,
@@ -2132,6 +2134,20 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
         r[i] = s[i] - omega * t[i];
     }
 }
+// the same with the NEXT iteration's p = r + beta (p - omega v) in the same pass (r stays in registers): one launch and one
+// read of r less per iteration; beta (sc[3]) is already the next iteration's (k_bicg_omega ran before)
+__global__ __launch_bounds__(256) void k_bicg_xrp(int64_t n, const double* __restrict__ sc, const double* __restrict__ ph,
+                                                  const double* __restrict__ sh, const double* __restrict__ s,
+                                                  const double* __restrict__ t, const double* __restrict__ v,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ p) {
+    const double alpha = sc[1], omega = sc[2], beta = sc[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * ph[i] + omega * sh[i];
+        const double rn = s[i] - omega * t[i];
+        r[i] = rn;
+        p[i] = rn + beta * (p[i] - omega * v[i]);
+    }
+}
 // sc[0..7] = (rho, alpha, omega, beta, rr, flags, 0, 0) at the start of a solve: rho = rr0 (rhat = r), beta = 0
 __global__ void k_bicg_init(double* __restrict__ sc, const double* __restrict__ rr0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2190,14 +2206,38 @@ __global__ __launch_bounds__(256) void k_restrict(int32_t nc, const int32_t* __r
     const int c = (int)(gid & 3);
     if (I >= nc) return;
     double s = 0.0;
-    for (int32_t k = m_ptr[I]; k < m_ptr[I + 1]; ++k) {
-        const int64_t d = 4 * (int64_t)m_idx[k] + c;
-        if (!free_mask || free_mask[d]) s += r[d];
+    const int32_t k0 = m_ptr[I], k1 = m_ptr[I + 1];
+    int32_t k = k0;
+    // aggregates have up to 8 members: all member ids first, then all residual entries (two round trips instead of
+    // one dependent pair per member)
+    for (; k + 7 < k1; k += 8) {
+        int32_t m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = m_idx[k + q];
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t d = 4 * (int64_t)m[q] + c;
+            v[q] = (!free_mask || free_mask[d]) ? r[d] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    if (k < k1) {
+        int32_t m[8];
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = (k + q < k1) ? m_idx[k + q] : -1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t d = 4 * (int64_t)(m[q] < 0 ? 0 : m[q]) + c;
+            v[q] = (m[q] >= 0 && (!free_mask || free_mask[d])) ? r[d] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
     }
     bc[4 * I + c] = s;
 }
-
-// x[i] += free_i * xc[agg[i]]
 __global__ __launch_bounds__(256) void k_prolong_add(int32_t n, const int32_t* __restrict__ agg,
                                                      const uint8_t* __restrict__ free_mask,
                                                      const double* __restrict__ xc, double* __restrict__ x) {
