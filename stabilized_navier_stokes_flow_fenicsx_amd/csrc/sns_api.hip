@@ -487,7 +487,6 @@ int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, con
     L.ap_nnz = M.nnz;
     SNS_TRY(dev_upload(&L.ap_rowptr, M.rowptr, h->stream));
     SNS_TRY(dev_upload(&L.ap_colind, M.colind, h->stream));
-    SNS_TRY(dev_upload(&L.ap_slot_row, M.slot_row, h->stream));
     SNS_TRY(dev_upload(&L.ap_ptr, M.ap_ptr, h->stream));
     SNS_TRY(dev_upload(&L.ap_idx, M.ap_idx, h->stream));
     return SNS_OK;
@@ -1145,10 +1144,8 @@ int pc_setup(sns_ctx* h) {
         }
         if (l + 1 < nl && L.ap_rowptr && h->opt.amg_fused_post && h->opt.pc_type == SNS_PC_AMG && lp_format(h, L) != 0 &&
             rows > 0) {
-            // numeric part of M = A P in the level's low-precision format
-            if (!L.ap_vals) SNS_TRY(dev_alloc(&L.ap_vals, (size_t)L.ap_nnz * 16));
-            hipLaunchKernelGGL(k_ap_sum, dim3((unsigned)((L.ap_nnz * 8 + 255) / 256)), dim3(256), 0, h->stream, L.ap_nnz,
-                               L.ap_ptr, L.ap_idx, L.vals, L.ap_slot_row, L.ap_colind, L.agg, L.free_mask, L.ap_vals);
+            // numeric part of M = A P, straight into the level's low-precision format (no fp64 copy of M)
+            const unsigned gq = (unsigned)((4 * (int64_t)rows + 255) / 256);
             if (lp_format(h, L) == 2) {
                 if (!L.ap_vals16) {
                     uint2* v16 = nullptr;
@@ -1156,12 +1153,12 @@ int pc_setup(sns_ctx* h) {
                     L.ap_vals16 = v16;
                     SNS_TRY(dev_alloc(&L.ap_scale16, (size_t)4 * std::max(1, L.n)));
                 }
-                hipLaunchKernelGGL(k_cvt_h16, dim3((unsigned)((4 * (int64_t)rows + 255) / 256)), dim3(256), 0, h->stream, rows,
-                                   L.ap_rowptr, L.ap_vals, (uint2*)L.ap_vals16, L.ap_scale16);
+                hipLaunchKernelGGL((k_ap_cvt<2>), dim3(gq), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_ptr,
+                                   L.ap_idx, L.vals, L.agg, L.free_mask, L.ap_vals16, L.ap_scale16);
             } else {
                 if (!L.ap_vals32) SNS_TRY(dev_alloc(&L.ap_vals32, (size_t)L.ap_nnz * 16));
-                hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(L.ap_nnz * 16)), dim3(256), 0, h->stream, L.ap_nnz * 16, L.ap_vals,
-                                   L.ap_vals32);
+                hipLaunchKernelGGL((k_ap_cvt<1>), dim3(gq), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_ptr,
+                                   L.ap_idx, L.vals, L.agg, L.free_mask, (void*)L.ap_vals32, (float*)nullptr);
             }
         }
         if (l + 1 < nl) {
@@ -2156,7 +2153,7 @@ int sns_destroy(sns_handle h) {
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
-        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_slot_row); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_vals); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);

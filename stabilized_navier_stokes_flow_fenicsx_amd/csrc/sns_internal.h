@@ -72,10 +72,9 @@ struct Level {
     int32_t* r_idx = nullptr;
     uint8_t* free_mask = nullptr;        // 4*n: 1 where dof takes part in transfer (level 0: !bc), else all 1
     // M = A P of this level for the fused first post-smoothing sweep (k_post_lp): pattern + gather lists (symbolic, once),
-    // fp64 values per numeric setup and their low-precision copy in the level's format
+    // values per numeric setup straight into the level's low-precision format (k_ap_cvt)
     int64_t ap_nnz = 0;
-    int32_t *ap_rowptr = nullptr, *ap_colind = nullptr, *ap_slot_row = nullptr, *ap_ptr = nullptr, *ap_idx = nullptr;
-    double* ap_vals = nullptr;
+    int32_t *ap_rowptr = nullptr, *ap_colind = nullptr, *ap_ptr = nullptr, *ap_idx = nullptr;
     float* ap_vals32 = nullptr;
     void* ap_vals16 = nullptr;
     float* ap_scale16 = nullptr;

@@ -61,9 +61,10 @@ template <int FMT, int FINE>
 __global__ void k_post_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                           const double* xc, const double* x_pre, const double* res1, const float* dinv32, double omega,
                           const int32_t* agg, const uint8_t* free_mask, double* y);
-__global__ void k_ap_sum(int64_t nnz_m, const int32_t* ap_ptr, const int32_t* ap_idx, const double* vals_f,
-                         const int32_t* slot_row_m, const int32_t* colind_m, const int32_t* agg, const uint8_t* free_mask,
-                         double* vals_m);
+template <int FMT>
+__global__ void k_ap_cvt(int32_t n_rows, const int32_t* rowptr_m, const int32_t* colind_m, const int32_t* ap_ptr,
+                         const int32_t* ap_idx, const double* vals_f, const int32_t* agg, const uint8_t* free_mask, void* out,
+                         float* scale);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
 __global__ void k_cvt_h16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);

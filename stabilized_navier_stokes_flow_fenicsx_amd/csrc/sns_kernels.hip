@@ -1800,46 +1800,69 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
                                              const int32_t*, const uint8_t*, double*);
 SNS_INST_POST(1, 0) SNS_INST_POST(1, 1) SNS_INST_POST(2, 0) SNS_INST_POST(2, 1)
 
-// M = A P for the fused post-smoothing sweep: M slot (i, J) <- sum of the fine blocks (i, j), j in aggregate J (gather
-// list ap_ptr / ap_idx, fixed order).  Dofs excluded from the transfer (level 0: Dirichlet dofs) have zero columns in A
-// except the unit diagonal (:74), so the only thing to take out is that 1.0 where the row's own node is in J.
-// 8 lanes per slot, one double2 each (as k_galerkin).
-__global__ __launch_bounds__(256) void k_ap_sum(int64_t nnz_m, const int32_t* __restrict__ ap_ptr,
+// M = A P for the fused post-smoothing sweep, straight into the level's low-precision format: M slot (i, J) <- sum of the
+// fine blocks (i, j), j in aggregate J (gather list ap_ptr / ap_idx, fixed order), no fp64 copy of M in between.
+// 4 lanes per fine block row (lane r = dof row r, as k_cvt_h16); FMT 2 walks the row twice -- the row's largest |entry| of M
+// first (the second walk finds the fine blocks in L2), then the scaled fp16 values in the pair-interleaved layout; FMT 1
+// writes fp32 in one walk.  Dofs excluded from the transfer (level 0: Dirichlet dofs) have zero columns in A except the unit
+// diagonal (:74), so the only thing to take out is that 1.0 where the row's own node is in J.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_ap_cvt(int32_t n_rows, const int32_t* __restrict__ rowptr_m,
+                                                const int32_t* __restrict__ colind_m, const int32_t* __restrict__ ap_ptr,
                                                 const int32_t* __restrict__ ap_idx, const double* __restrict__ vals_f,
-                                                const int32_t* __restrict__ slot_row_m,
-                                                const int32_t* __restrict__ colind_m, const int32_t* __restrict__ agg,
-                                                const uint8_t* __restrict__ free_mask, double* __restrict__ vals_m) {
+                                                const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
+                                                void* __restrict__ out_v, float* __restrict__ scale) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t s = gid >> 3;
-    const int t = (int)(gid & 7);
-    if (s >= nnz_m) return;
-    double2 v0 = make_double2(0.0, 0.0), v1 = v0;
-    const int32_t k1 = ap_ptr[s + 1];
-    int32_t k = ap_ptr[s];
-    for (; k + 1 < k1; k += 2) {
-        const int32_t f0 = ap_idx[k], f1 = ap_idx[k + 1];
-        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)f0 * 16)[t];
-        const double2 b = reinterpret_cast<const double2*>(vals_f + (int64_t)f1 * 16)[t];
-        v0.x += a.x; v0.y += a.y;
-        v1.x += b.x; v1.y += b.y;
-    }
-    if (k < k1) {
-        const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)ap_idx[k] * 16)[t];
-        v0.x += a.x; v0.y += a.y;
-    }
-    double2 v = make_double2(v0.x + v1.x, v0.y + v1.y);
-    if (free_mask) {
-        const int32_t i = slot_row_m[s];
-        if (agg[i] == colind_m[s]) {
-            const int c = t >> 1;                          // lane t holds entries (c, 2*(t&1)) and (c, 2*(t&1)+1)
-            if (!free_mask[4 * (int64_t)i + c] && (t & 1) == (c >> 1)) {
-                if (c & 1) v.y -= 1.0;
-                else v.x -= 1.0;
-            }
+    const int64_t row = gid >> 2;
+    const int r = (int)(gid & 3);
+    if (row >= n_rows) return;
+    const int32_t s = rowptr_m[row], e = rowptr_m[row + 1];
+    const int32_t own = agg[row];
+    const bool fixed = free_mask && !free_mask[4 * row + r];
+    auto slot_sum = [&](int32_t q, double (&v)[4]) {
+        v[0] = v[1] = v[2] = v[3] = 0.0;
+        for (int32_t k = ap_ptr[q]; k < ap_ptr[q + 1]; ++k) {
+            const double* a = vals_f + 16 * (int64_t)ap_idx[k] + 4 * r;
+            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
         }
+        if (fixed && colind_m[q] == own) v[r] -= 1.0;
+    };
+    if (FMT == 1) {
+        float4* out = reinterpret_cast<float4*>(out_v);
+        for (int32_t q = s; q < e; ++q) {
+            double v[4];
+            slot_sum(q, v);
+            out[(int64_t)q * 4 + r] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        }
+        return;
     }
-    reinterpret_cast<double2*>(vals_m + s * 16)[t] = v;
+    double m = 0.0;
+    for (int32_t q = s; q < e; ++q) {
+        double v[4];
+        slot_sum(q, v);
+        m = fmax(m, fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3]))));
+    }
+    const float sc = (float)m;
+    const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+    scale[4 * row + r] = sc;
+    uint2* out = reinterpret_cast<uint2*>(out_v);
+    const int32_t cnt = e - s;
+    for (int32_t q = s; q < e; ++q) {
+        double v[4];
+        slot_sum(q, v);
+        f16x4_t hv;
+        hv.x = (_Float16)(float)(v[0] * inv); hv.y = (_Float16)(float)(v[1] * inv);
+        hv.z = (_Float16)(float)(v[2] * inv); hv.w = (_Float16)(float)(v[3] * inv);
+        const int32_t j = q - s;
+        const bool paired = (j | 1) < cnt;
+        const int64_t dst = paired ? ((int64_t)s * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)q * 4 + r);
+        out[dst] = *reinterpret_cast<const uint2*>(&hv);
+    }
 }
+template __global__ void k_ap_cvt<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
+                                     const int32_t*, const uint8_t*, void*, float*);
+template __global__ void k_ap_cvt<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
+                                     const int32_t*, const uint8_t*, void*, float*);
 
 // fp16 copy of a BSR4 matrix with one scale per dof row, in the pair-interleaved layout k_spmv_lp<FMT 2> reads:
 // 4 lanes per block row, lane r owns dof row 4*row + r.  Block j of a row (j = k - rowptr[row]) that has a partner
