@@ -372,6 +372,11 @@ def test_rccl_path_single_rank(gpu):
         Us, rs = Ps.stokes_solve()
         assert rd.reason > 0 and rd.its == rs.its
         assert float((Pd.gather(Ud) - Us).norm() / Us.norm()) < 1e-12
+        # what bench.py prints as transport / rccl_ranks: RCCL itself reports the communicator's size
+        ci, cs = Pd.comm_info(), Ps.comm_info()
+        assert ci == dict(transport="rccl", rank=0, nranks=1, rccl_ranks=1)
+        assert cs["transport"] == "none" and cs["rccl_ranks"] == 0
+        assert Pd.counters()["allreduces"] >= 2 * rd.its and Ps.counters()["allreduces"] == 0
         wd, nd_ = Pd.newton_solve(Ud.clone())
         ws, ns_ = Ps.newton_solve(Us.clone())
         assert nd_.its == ns_.its and nd_.reason == ns_.reason
