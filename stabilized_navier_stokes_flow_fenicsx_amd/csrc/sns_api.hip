@@ -1444,6 +1444,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
     }
     if (fused_post) {
+        // (the post-sweep is done; a partitioned fine level got its neighbours' corrections through xc)
     } else if (px && l == 0 && nu == 1) {
         // the single post-smoothing sweep of the fine level with the neighbours' corrected iterate: halo of `cur`
         // overlapped with the interior rows of the sweep
