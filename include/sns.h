@@ -131,7 +131,7 @@ typedef struct {
                                once from the same guess with every level's block-Jacobi damping scaled by 0.7 (see
                                sns_krylov_solve); 0: the failed reason is reported and that is it, as PETSc does */
     int    amg_retry_stall_its; /* with amg_retry_damping: the first BiCGStab attempt also counts as broken down when its best
-                               residual norm has not improved by 10 % for this many iterations (200; 0 = breakdown / NaN only).
+                               residual norm has not halved for this many iterations (100; 0 = breakdown / NaN only).
                                An over-relaxed smoother makes BiCGStab stagnate far more often than break down outright */
     int    halo_overlap;    /* multi-GPU: 1 (default) = level-0 passes compute their interior rows on a second stream while the
                                halo exchange is in flight and the boundary rows after it; 0 = exchange, then one full pass
