@@ -142,6 +142,10 @@ typedef struct {
                                level; same low-precision format as the level matrix): z = (x1 + P xc) + w Dinv (r1 - M xc).
                                The same linear operator as prolongation + sweep up to rounding.  Needs amg_f32_matrix != 0;
                                0 = prolongation kernel + a full sweep over A */
+    int    amg_nu_scale_with_size; /* 1 (default): more sweeps on level 2 and the deeper levels of LARGE problems, where they cost
+                               next to nothing and the plain-aggregation V-cycle loses convergence with its depth: from 2.5 M fine
+                               rows (all ranks together) amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6 (81 M tets on
+                               one GPU: 73 / 82 -> 53 / 57 BiCGStab iterations per Newton step, -25 % time).  0 = the counts as given */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

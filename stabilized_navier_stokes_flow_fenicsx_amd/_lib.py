@@ -39,6 +39,7 @@ class SnsOptions(C.Structure):
         ("amg_retry_stall_its", C.c_int),
         ("halo_overlap", C.c_int),
         ("amg_fused_post", C.c_int),
+        ("amg_nu_scale_with_size", C.c_int),
     ]
 
 

@@ -73,6 +73,7 @@ struct sns_ctx {
     // mesh (dim 3: tets; dim 2: triangles in a stride-4 connectivity, z component a Dirichlet dof)
     int dim = 3;
     int32_t n = 0, n_owned = 0;
+    int64_t n_global_fine = 0;                   // fine-level rows over all ranks (set when the hierarchy is built)
     int64_t E = 0;
     int32_t* tets = nullptr;
     double* pts = nullptr;
@@ -631,6 +632,11 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     const bool dist = c && c->active() && c->nranks > 1;
     HostPattern cur = fine;
     int32_t n_owned = h->n_owned;
+    {
+        double ng[1] = {(double)h->n_owned};
+        SNS_TRY(global_sum(h, ng, 1));
+        h->n_global_fine = (int64_t)ng[0];
+    }
     h->ghost_gid.assign(1, {});
     h->ghost_own.assign(1, {});
     const int per_rank_coarse = dist ? std::max(1, o.amg_coarse_size / c->nranks) : o.amg_coarse_size;
@@ -970,11 +976,20 @@ inline bool level_sx(const sns_ctx* h, const Level& L) { return L.xg && L.n_owne
 // sweeps per level: the fine level is the expensive one (1 sweep); level 1 and 2 are cheap and are where
 // plain aggregation needs the smoothing (4 and 6); levels >= 3 are launch-bound (2).  Measured on the
 // 10 M-tet Jacobian: (1,4,6,2) 40-42 its / 180-186 ms; (1,4,4,4) 45 / 204; (2,2,2,2) 54 / 323.
+// Large problems (amg_nu_scale_with_size): the plain-aggregation V-cycle loses convergence with its depth, and on a big mesh the
+// levels >= 2 cost next to nothing -- measured on one GPU (profiles/r3_deep_sweeps.txt): 81 M tets 73 / 82 -> 53 / 57 iterations and
+// 1743 -> 1303 ms per Newton step with 10 + 10 sweeps on level 2 and 8 + 8 below instead of 6 + 6 and 2 + 2; 24 M tets 52 / 55 -> 45 / 49
+// with 8 + 8 and 4 + 4; at 10 M tets the extra latency-bound passes cost what they save, so the schedule follows the GLOBAL fine size.
 inline int level_nu(const sns_ctx* h, int l) {
     const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
+    int add_l2 = 0, add_deep = 0;
+    if (h->opt.amg_nu_scale_with_size) {
+        if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
+        else if (h->n_global_fine >= 2500000) { add_l2 = 2; add_deep = 2; }
+    }
     int nu = std::max(1, h->opt.amg_nu);
-    if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep;
-    else if (ll == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2;
+    if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep + add_deep;
+    else if (ll == 2 && h->opt.amg_nu_l2 > 0) nu = h->opt.amg_nu_l2 + add_l2;
     else if (ll >= 1 && h->opt.amg_nu_coarse > 0) nu = h->opt.amg_nu_coarse;
     return nu;
 }
@@ -1230,6 +1245,7 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_nu_l1_pre); sig.push_back(h->opt.amg_nu_l1_post);
     sig.push_back(h->opt.amg_f32_matrix);
     sig.push_back(h->opt.amg_fused_post);
+    sig.push_back(h->opt.amg_nu_scale_with_size);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
         if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
@@ -1979,6 +1995,7 @@ void sns_default_options(sns_options* o) {
     o->amg_retry_stall_its = 100;
     o->halo_overlap = 1;
     o->amg_fused_post = 1;
+    o->amg_nu_scale_with_size = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }

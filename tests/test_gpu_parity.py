@@ -1107,6 +1107,27 @@ def test_fused_post_sweep_is_the_same_preconditioner(gpu, kind):
     P.close()
 
 
+def test_large_meshes_get_more_deep_level_sweeps(gpu):
+    """amg_nu_scale_with_size: from 2.5 M fine rows on, level 2 and the deeper levels run more sweeps (they cost next to
+    nothing there and the plain-aggregation V-cycle loses convergence with its depth).  14.7 M-tet duct (2.56 M nodes), Re 200:
+    fewer BiCGStab iterations than with the counts as given, same converged step (measured: 46 / 48 against 49 / 52 and, at
+    81 M tets, 53 / 57 against 73 / 82 -- profiles/r3_sizes.txt)."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
+    part = PT.duct_slab_part((340, 85, 85), 4.0, 0, 1)            # slab builder: no boundary-facet sort over the whole mesh
+    assert part.mesh.num_nodes >= 2_500_000
+    out = {}
+    for scale in (1, 0):
+        P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=200.0, snes_max_it=1, amg_nu_scale_with_size=scale)
+        U, r = P.stokes_solve()
+        w, n = P.newton_solve(U.clone())
+        assert r.reason > 0 and n.reason in (2, 3, 4, -5) and n.fnorms[-1] < n.fnorms[0]      # -5: snes_max_it = 1 reached
+        out[scale] = (r.its, n.ksp_its, n.fnorms[-1])
+        P.close()
+    print(f"  14.7 M tets: stokes / first Newton step iterations {out[1][:2]} with the size-scaled schedule, {out[0][:2]} without")
+    assert out[1][0] < out[0][0] and out[1][1] < out[0][1]
+    assert abs(out[1][2] - out[0][2]) < 1e-3 * out[0][2]          # the same Newton step either way
+
+
 def test_unstructured_delaunay_mesh_iteration_bound(gpu):
     """The reference's production meshes are gmsh Delaunay meshes (image2gmsh3D.py:445-486), not Kuhn boxes: the
     two-stream channel (Re 50, BASELINE config 4's physics) on a 1.05 M-tet Delaunay mesh (body-centred lattice: the
