@@ -144,8 +144,9 @@ typedef struct {
                                0 = prolongation kernel + a full sweep over A */
     int    amg_nu_scale_with_size; /* 1 (default): more sweeps on level 2 and the deeper levels of LARGE problems, where they cost
                                next to nothing and the plain-aggregation V-cycle loses convergence with its depth: from 2.5 M fine
-                               rows (all ranks together) amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6 (81 M tets on
-                               one GPU: 73 / 82 -> 53 / 57 BiCGStab iterations per Newton step, -25 % time).  0 = the counts as given */
+                               rows (all ranks together) amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6, from 20 M rows + 6
+                               and + 10 (81 M tets on one GPU: 73 / 82 -> 53 / 57 BiCGStab iterations per Newton step, -25 % time;
+                               192 M tets: 95 / 108 -> 55 / 66).  0 = the counts as given */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

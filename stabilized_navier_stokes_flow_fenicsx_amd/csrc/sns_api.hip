@@ -984,7 +984,8 @@ inline int level_nu(const sns_ctx* h, int l) {
     const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
     int add_l2 = 0, add_deep = 0;
     if (h->opt.amg_nu_scale_with_size) {
-        if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
+        if (h->n_global_fine >= 20000000) { add_l2 = 6; add_deep = 10; }       // 192 M tets: 63 / 71 -> 55 / 66, -10 % time
+        else if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
         else if (h->n_global_fine >= 2500000) { add_l2 = 2; add_deep = 2; }
     }
     int nu = std::max(1, h->opt.amg_nu);
