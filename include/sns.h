@@ -144,7 +144,8 @@ typedef struct {
                                0 = prolongation kernel + a full sweep over A */
     int    amg_nu_scale_with_size; /* 1 (default): more sweeps on level 2 and the deeper levels of LARGE problems, where they cost
                                next to nothing and the plain-aggregation V-cycle loses convergence with its depth: from 2.5 M fine
-                               rows (all ranks together) amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6, from 20 M rows + 6
+                               rows (all ranks together) -- or on a hierarchy of >= 7 levels whose first coarsening keeps more than
+                               one row in six, i.e. an unstructured mesh -- amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6, from 20 M rows + 6
                                and + 10 (81 M tets on one GPU: 73 / 82 -> 53 / 57 BiCGStab iterations per Newton step, -25 % time;
                                192 M tets: 95 / 108 -> 55 / 66).  0 = the counts as given */
 } sns_options;
@@ -275,6 +276,10 @@ int sns_get_counters(sns_handle h, int64_t out[8]);
  * out[2] = ranks the handle was attached with, out[3] = ranks RCCL itself reports (ncclCommCount; 0 without RCCL):
  * bench.py prints it so that "did RCCL see N ranks" can be read off the result line */
 int sns_comm_info(sns_handle h, int32_t out[4]);
+/* the AMG hierarchy as built (what PETSc's -ksp_view prints of a PCGAMG/PCMG): *nlevels levels (at most 16 reported; a
+ * partitioned handle counts its replicated tail copy), per level the rows this rank solves for, the 4x4 blocks of its
+ * operator, the sweeps per half cycle level_nu gives it (after amg_nu_scale_with_size) and the block-Jacobi damping in use */
+int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t blocks[16], int32_t sweeps[16], double omega[16]);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot,

@@ -93,6 +93,7 @@ _SIGNATURES = [
     ("sns_get_timings", C.c_int, [_H, C.POINTER(SnsTimings)]),
     ("sns_get_counters", C.c_int, [_H, C.POINTER(C.c_int64)]),
     ("sns_comm_info", C.c_int, [_H, C.POINTER(C.c_int32)]),
+    ("sns_get_hierarchy", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("sns_reset_timings", C.c_int, [_H]),
     ("sns_time_kernels", C.c_int, [_H, C.c_int]),
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

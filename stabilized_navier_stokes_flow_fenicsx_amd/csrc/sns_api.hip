@@ -984,9 +984,17 @@ inline int level_nu(const sns_ctx* h, int l) {
     const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;      // the replicated copy is not a new level
     int add_l2 = 0, add_deep = 0;
     if (h->opt.amg_nu_scale_with_size) {
+        // an unstructured mesh: the greedy aggregation reaches ~4.6 nodes per aggregate on a Delaunay mesh where a Kuhn box
+        // gives 7.7-8.0 (sns_get_hierarchy), so that its hierarchy is as deep at 0.4 M rows as the structured one at 1.7 M and
+        // its coarse operators are denser -- it gains from the first tier of extra sweeps already: config 4u (5 M-tet
+        // body-centred Delaunay channel, 7 levels) 71 -> 58 iterations per Newton step and 145-148 -> 131-134 ms, where
+        // the structured 10 M-tet duct (7 levels as well) pays +3 % for 43.5 -> 43.0 (scripts/gpu_r3_tierA.py)
+        const int nlev = (int)h->levels.size() - (h->rep_level > 0 ? 1 : 0);
+        const bool small_aggregates = h->levels.size() > 1 && h->levels[1].n_owned > 0
+                                      && (double)h->levels[0].n_owned < 6.0 * h->levels[1].n_owned;
         if (h->n_global_fine >= 20000000) { add_l2 = 6; add_deep = 10; }       // 192 M tets: 63 / 71 -> 55 / 66, -10 % time
         else if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
-        else if (h->n_global_fine >= 2500000) { add_l2 = 2; add_deep = 2; }
+        else if (h->n_global_fine >= 2500000 || (nlev >= 7 && small_aggregates)) { add_l2 = 2; add_deep = 2; }
     }
     int nu = std::max(1, h->opt.amg_nu);
     if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep + add_deep;
@@ -2563,6 +2571,19 @@ int sns_comm_info(sns_handle h, int32_t out[4]) {
         int cnt = 0;
         NCCL_TRY(ncclCommCount(c->nccl, &cnt));
         out[3] = cnt;
+    }
+    return SNS_OK;
+}
+int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t blocks[16], int32_t sweeps[16], double omega[16]) {
+    if (!h || !nlevels) return SNS_E_ARG;
+    const int nl = (int)std::min<size_t>(16, h->levels.size());
+    *nlevels = nl;
+    for (int l = 0; l < nl; ++l) {
+        const Level& L = h->levels[l];
+        if (rows) rows[l] = L.n_owned;
+        if (blocks) blocks[l] = L.nnzb;
+        if (sweeps) sweeps[l] = l + 1 < (int)h->levels.size() ? level_nu(h, l) : 0;      // the coarsest level is a dense inverse
+        if (omega) omega[l] = L.omega;
     }
     return SNS_OK;
 }

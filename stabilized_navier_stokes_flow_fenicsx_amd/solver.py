@@ -329,6 +329,13 @@ class FlowProblem:
         check(self.lib.sns_comm_info(self.h, c))
         return dict(transport={0: "none", 1: "rccl", 2: "team"}[c[0]], rank=c[1], nranks=c[2], rccl_ranks=c[3])
 
+    def hierarchy(self):
+        """The AMG hierarchy as built: one dict per level (rows, 4x4 blocks, sweeps per half cycle, block-Jacobi damping)."""
+        nl = C.c_int32()
+        rows, blocks, nu, om = (C.c_int64 * 16)(), (C.c_int64 * 16)(), (C.c_int32 * 16)(), (C.c_double * 16)()
+        check(self.lib.sns_get_hierarchy(self.h, C.byref(nl), rows, blocks, nu, om))
+        return [dict(rows=rows[l], blocks=blocks[l], sweeps=nu[l], omega=om[l]) for l in range(nl.value)]
+
     def reset_timings(self):
         check(self.lib.sns_reset_timings(self.h))
 

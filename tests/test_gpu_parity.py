@@ -1147,6 +1147,17 @@ def test_unstructured_delaunay_mesh_iteration_bound(gpu):
         assert r.reason > 0 and n.reason > 0 and n.fnorms[-1] < 1e-8
         c = P.counters()
         assert c["damping_retries"] == 0                                           # no help from the retry path
+        # the hierarchy as built (sns_get_hierarchy, the -ksp_view of this preconditioner): rows shrink level by level, the
+        # fine level runs 1 sweep, the coarsest is a dense inverse (0), the damping is a proper under-relaxation; the
+        # greedy aggregation reaches ~8 nodes per aggregate on the Kuhn box and ~4.6 on the Delaunay mesh (which is what
+        # amg_nu_scale_with_size keys its first tier on for hierarchies of >= 7 levels: 6 levels here, nothing added)
+        H = P.hierarchy()
+        assert len(H) == P.timings().amg_levels and H[0]["rows"] == m.num_nodes and H[0]["blocks"] == P.sizes()["nnzb"]
+        assert all(a["rows"] > 3 * b["rows"] for a, b in zip(H, H[1:]))
+        assert [L["sweeps"] for L in H[:3]] == [1, 4, 6] and all(L["sweeps"] == 2 for L in H[3:-1]) and H[-1]["sweeps"] == 0
+        assert all(0.3 < L["omega"] <= 0.8 for L in H)
+        ratio = H[0]["rows"] / H[1]["rows"]
+        assert (7.0 < ratio <= 8.0) if name == "structured" else (4.0 < ratio < 6.0)
         out[name] = (m.num_nodes, r.its, n.ksp_its / n.its)
         print(f"  {name}: {m.num_tets} tets, {m.num_nodes} nodes, stokes its {r.its}, ksp its per Newton step {n.ksp_its / n.its:.1f}")
         P.close()
