@@ -1225,6 +1225,26 @@ int pc_setup(sns_ctx* h) {
     return SNS_OK;
 }
 
+// sweeps before / after the coarse-grid correction on level l (the first pre-sweep is omega D^-1 b)
+inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
+    const int nu = level_nu(h, l);
+    nu_pre = nu_post = nu;
+    const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;
+    if (ll == 1) {
+        // level 1: asymmetric sweep counts (amg_nu_l1_pre / amg_nu_l1_post).  Automatic (both options 0): a single-GPU handle
+        // runs 1 + (nu + 2) sweeps -- post-smoothing is the more valuable half under a piecewise-constant prolongation, 1 + 6
+        // needs the iterations of 4 + 4 with one level-1 pass less (-3 % per Newton step on the 10 M-tet duct, neutral
+        // elsewhere); a partitioned handle keeps nu + nu, its post-sweeps being rank-local (1 + 6 costs 8-11 % more
+        // iterations there)
+        const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
+        if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
+            nu_pre = 1;
+            nu_post = nu + 2;
+        }
+        if (h->opt.amg_nu_l1_pre > 0) nu_pre = h->opt.amg_nu_l1_pre;
+        if (h->opt.amg_nu_l1_post > 0) nu_post = h->opt.amg_nu_l1_post;
+    }
+}
 int vcycle(sns_ctx* h, int l, const double* b, double* x);
 // First level (>= 1) small enough that its kernels are launch-bound rather than bandwidth-bound: it and everything
 // below run as one graph.  10 M tets: level 2 (36 k rows; level 1 has 218 k rows = 46 us per sweep); 1 M tets: level 1.
@@ -1359,24 +1379,8 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         return SNS_OK;
     }
     const int nu = level_nu(h, l);
-    // level 1: asymmetric sweep counts (amg_nu_l1_pre / amg_nu_l1_post; the first pre-sweep is omega D^-1 b)
     int nu_pre = nu, nu_post = nu;
-    {
-        const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;
-        if (ll == 1) {
-            // automatic (both options 0): a single-GPU handle runs 1 + (nu + 2) sweeps -- post-smoothing is the more valuable
-            // half under a piecewise-constant prolongation, 1 + 6 needs the iterations of 4 + 4 with one level-1 pass less
-            // (-3 % per Newton step on the 10 M-tet duct, neutral elsewhere); a partitioned handle keeps nu + nu, its
-            // post-sweeps being rank-local (1 + 6 costs 8-11 % more iterations there)
-            const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
-            if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
-                nu_pre = 1;
-                nu_post = nu + 2;
-            }
-            if (h->opt.amg_nu_l1_pre > 0) nu_pre = h->opt.amg_nu_l1_pre;
-            if (h->opt.amg_nu_l1_post > 0) nu_post = h->opt.amg_nu_l1_post;
-        }
-    }
+    level_sweeps(h, l, nu_pre, nu_post);
     const int nswaps = nu_pre - 1 + nu_post;
     double* cur = (nswaps & 1) ? h->pong[l] : x;
     double* oth = (nswaps & 1) ? x : h->pong[l];
