@@ -490,6 +490,28 @@ int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, con
     SNS_TRY(dev_upload(&L.ap_colind, M.colind, h->stream));
     SNS_TRY(dev_upload(&L.ap_ptr, M.ap_ptr, h->stream));
     SNS_TRY(dev_upload(&L.ap_idx, M.ap_idx, h->stream));
+    // the same relation per fine block for k_lp_copies16, which accumulates M from the row it holds in registers
+    std::vector<uint64_t> nib((size_t)n_rows);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < n_rows; ++i) {
+        const int32_t s = fine.rowptr[i], cnt = fine.rowptr[i + 1] - s;
+        const int32_t m0 = M.rowptr[i], cm = M.rowptr[i + 1] - m0;
+        uint64_t v = ~0ull;
+        if (cnt <= 16 && cm <= 8) {
+            v = 0;
+            for (int32_t j = 0; j < 16; ++j) {
+                uint64_t t = 15;
+                if (j < cnt) {
+                    const int32_t J = agg_all[fine.colind[s + j]];
+                    if (J >= 0)
+                        t = (uint64_t)(std::lower_bound(M.colind.begin() + m0, M.colind.begin() + m0 + cm, J) - (M.colind.begin() + m0));
+                }
+                v |= t << (4 * j);
+            }
+        }
+        nib[i] = v;
+    }
+    SNS_TRY(dev_upload(&L.ap_nib, nib, h->stream));
     return SNS_OK;
 }
 
@@ -1127,9 +1149,27 @@ int pc_setup(sns_ctx* h) {
                     L.vals16 = v16;
                     SNS_TRY(dev_alloc(&L.scale16, (size_t)4 * std::max(1, L.n)));
                 }
-                if (rows > 0)
-                    hipLaunchKernelGGL(k_cvt_h16, dim3((unsigned)((4 * (int64_t)rows + 255) / 256)), dim3(256), 0, h->stream,
-                                       rows, L.rowptr, L.vals, (uint2*)L.vals16, L.scale16);
+                // ONE pass over the level's fp64 operator writes its fp16 copy and, where the level has one, the fp16 copy of
+                // M = A P for the fused post-smoothing sweep (k_lp_copies16)
+                const bool with_m = l + 1 < nl && L.ap_rowptr && L.ap_nib && h->opt.amg_fused_post;
+                if (with_m && !L.ap_vals16) {
+                    uint2* v16 = nullptr;
+                    SNS_TRY(dev_alloc(&v16, (size_t)L.ap_nnz * 4));
+                    L.ap_vals16 = v16;
+                    SNS_TRY(dev_alloc(&L.ap_scale16, (size_t)4 * std::max(1, L.n)));
+                }
+                if (rows > 0) {
+                    const unsigned grid = (unsigned)((rows + 31) / 32);
+                    if (with_m)
+                        hipLaunchKernelGGL((k_lp_copies16<1>), dim3(grid), dim3(128), 0, h->stream, rows, L.rowptr, L.vals,
+                                           (uint2*)L.vals16, L.scale16, L.ap_rowptr, L.ap_colind, L.ap_ptr, L.ap_idx, L.ap_nib, L.agg,
+                                           L.free_mask, (uint2*)L.ap_vals16, L.ap_scale16);
+                    else
+                        hipLaunchKernelGGL((k_lp_copies16<0>), dim3(grid), dim3(128), 0, h->stream, rows, L.rowptr, L.vals,
+                                           (uint2*)L.vals16, L.scale16, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                                           (const int32_t*)nullptr, (const int32_t*)nullptr, (const uint64_t*)nullptr,
+                                           (const int32_t*)nullptr, (const uint8_t*)nullptr, (uint2*)nullptr, (float*)nullptr);
+                }
             }
             bool want32 = h->opt.amg_f32_matrix != 2;
 #ifdef SNS_HARNESS
@@ -1171,18 +1211,11 @@ int pc_setup(sns_ctx* h) {
             // numeric part of M = A P, straight into the level's low-precision format (no fp64 copy of M)
             const unsigned gq = (unsigned)((4 * (int64_t)rows + 255) / 256);
             if (lp_format(h, L) == 2) {
-                if (!L.ap_vals16) {
-                    uint2* v16 = nullptr;
-                    SNS_TRY(dev_alloc(&v16, (size_t)L.ap_nnz * 4));
-                    L.ap_vals16 = v16;
-                    SNS_TRY(dev_alloc(&L.ap_scale16, (size_t)4 * std::max(1, L.n)));
-                }
-                hipLaunchKernelGGL((k_ap_cvt<2>), dim3(gq), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_ptr,
-                                   L.ap_idx, L.vals, L.agg, L.free_mask, L.ap_vals16, L.ap_scale16);
+                // (written together with the fp16 copy of A above)
             } else {
                 if (!L.ap_vals32) SNS_TRY(dev_alloc(&L.ap_vals32, (size_t)L.ap_nnz * 16));
-                hipLaunchKernelGGL((k_ap_cvt<1>), dim3(gq), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_ptr,
-                                   L.ap_idx, L.vals, L.agg, L.free_mask, (void*)L.ap_vals32, (float*)nullptr);
+                hipLaunchKernelGGL(k_ap_cvt32, dim3(gq), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_ptr,
+                                   L.ap_idx, L.vals, L.agg, L.free_mask, (float4*)L.ap_vals32);
             }
         }
         if (l + 1 < nl) {
@@ -2185,7 +2218,7 @@ int sns_destroy(sns_handle h) {
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
-        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);

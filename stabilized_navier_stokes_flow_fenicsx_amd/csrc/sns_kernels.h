@@ -61,12 +61,13 @@ template <int FMT, int FINE>
 __global__ void k_post_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                           const double* xc, const double* x_pre, const double* res1, const float* dinv32, double omega,
                           const int32_t* agg, const uint8_t* free_mask, double* y);
-template <int FMT>
-__global__ void k_ap_cvt(int32_t n_rows, const int32_t* rowptr_m, const int32_t* colind_m, const int32_t* ap_ptr,
-                         const int32_t* ap_idx, const double* vals_f, const int32_t* agg, const uint8_t* free_mask, void* out,
-                         float* scale);
+__global__ void k_ap_cvt32(int32_t n_rows, const int32_t* rowptr_m, const int32_t* colind_m, const int32_t* ap_ptr,
+                           const int32_t* ap_idx, const double* vals_f, const int32_t* agg, const uint8_t* free_mask, float4* out);
+template <int WITH_M>
+__global__ void k_lp_copies16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale,
+                              const int32_t* rowptr_m, const int32_t* colind_m, const int32_t* ap_ptr, const int32_t* ap_idx,
+                              const uint64_t* ap_nib, const int32_t* agg, const uint8_t* free_mask, uint2* out_m, float* scale_m);
 __global__ void k_cvt_f32(int64_t n, const double* x, float* y);
-__global__ void k_cvt_h16(int32_t n_rows, const int32_t* rowptr, const double* vals, uint2* out, float* scale);
 __global__ void k_dinv(int32_t n, const int32_t* diag, const double* vals, double* dinv);
 __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double omega, double* z);
 __global__ void k_bjacobi32(int32_t n, const float* dinv32, const double* r, double omega, double* z);

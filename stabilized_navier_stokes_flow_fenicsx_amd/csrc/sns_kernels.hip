@@ -1800,18 +1800,15 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
                                              const int32_t*, const uint8_t*, double*);
 SNS_INST_POST(1, 0) SNS_INST_POST(1, 1) SNS_INST_POST(2, 0) SNS_INST_POST(2, 1)
 
-// M = A P for the fused post-smoothing sweep, straight into the level's low-precision format: M slot (i, J) <- sum of the
-// fine blocks (i, j), j in aggregate J (gather list ap_ptr / ap_idx, fixed order), no fp64 copy of M in between.
-// 4 lanes per fine block row (lane r = dof row r, as k_cvt_h16); FMT 2 walks the row twice -- the row's largest |entry| of M
-// first (the second walk finds the fine blocks in L2), then the scaled fp16 values in the pair-interleaved layout; FMT 1
-// writes fp32 in one walk.  Dofs excluded from the transfer (level 0: Dirichlet dofs) have zero columns in A except the unit
-// diagonal (:74), so the only thing to take out is that 1.0 where the row's own node is in J.
-template <int FMT>
-__global__ __launch_bounds__(256) void k_ap_cvt(int32_t n_rows, const int32_t* __restrict__ rowptr_m,
-                                                const int32_t* __restrict__ colind_m, const int32_t* __restrict__ ap_ptr,
-                                                const int32_t* __restrict__ ap_idx, const double* __restrict__ vals_f,
-                                                const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
-                                                void* __restrict__ out_v, float* __restrict__ scale) {
+// M = A P for the fused post-smoothing sweep in fp32 (amg_f32_matrix = 1; the fp16 format is written by k_lp_copies16 below):
+// M slot (i, J) <- sum of the fine blocks (i, j), j in aggregate J (gather list ap_ptr / ap_idx, fixed order), no fp64 copy of M
+// in between.  4 lanes per fine block row (lane r = dof row r).  Dofs excluded from the transfer (level 0: Dirichlet dofs) have
+// zero columns in A except the unit diagonal (:74), so the only thing to take out is that 1.0 where the row's own node is in J.
+__global__ __launch_bounds__(256) void k_ap_cvt32(int32_t n_rows, const int32_t* __restrict__ rowptr_m,
+                                                  const int32_t* __restrict__ colind_m, const int32_t* __restrict__ ap_ptr,
+                                                  const int32_t* __restrict__ ap_idx, const double* __restrict__ vals_f,
+                                                  const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
+                                                  float4* __restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t row = gid >> 2;
     const int r = (int)(gid & 3);
@@ -1819,82 +1816,185 @@ __global__ __launch_bounds__(256) void k_ap_cvt(int32_t n_rows, const int32_t* _
     const int32_t s = rowptr_m[row], e = rowptr_m[row + 1];
     const int32_t own = agg[row];
     const bool fixed = free_mask && !free_mask[4 * row + r];
-    auto slot_sum = [&](int32_t q, double (&v)[4]) {
-        v[0] = v[1] = v[2] = v[3] = 0.0;
+    for (int32_t q = s; q < e; ++q) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
         for (int32_t k = ap_ptr[q]; k < ap_ptr[q + 1]; ++k) {
             const double* a = vals_f + 16 * (int64_t)ap_idx[k] + 4 * r;
             v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
         }
         if (fixed && colind_m[q] == own) v[r] -= 1.0;
-    };
-    if (FMT == 1) {
-        float4* out = reinterpret_cast<float4*>(out_v);
-        for (int32_t q = s; q < e; ++q) {
-            double v[4];
-            slot_sum(q, v);
-            out[(int64_t)q * 4 + r] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-        }
-        return;
-    }
-    double m = 0.0;
-    for (int32_t q = s; q < e; ++q) {
-        double v[4];
-        slot_sum(q, v);
-        m = fmax(m, fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3]))));
-    }
-    const float sc = (float)m;
-    const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
-    scale[4 * row + r] = sc;
-    uint2* out = reinterpret_cast<uint2*>(out_v);
-    const int32_t cnt = e - s;
-    for (int32_t q = s; q < e; ++q) {
-        double v[4];
-        slot_sum(q, v);
-        f16x4_t hv;
-        hv.x = (_Float16)(float)(v[0] * inv); hv.y = (_Float16)(float)(v[1] * inv);
-        hv.z = (_Float16)(float)(v[2] * inv); hv.w = (_Float16)(float)(v[3] * inv);
-        const int32_t j = q - s;
-        const bool paired = (j | 1) < cnt;
-        const int64_t dst = paired ? ((int64_t)s * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)q * 4 + r);
-        out[dst] = *reinterpret_cast<const uint2*>(&hv);
+        out[(int64_t)q * 4 + r] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
     }
 }
-template __global__ void k_ap_cvt<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
-                                     const int32_t*, const uint8_t*, void*, float*);
-template __global__ void k_ap_cvt<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
-                                     const int32_t*, const uint8_t*, void*, float*);
 
-// fp16 copy of a BSR4 matrix with one scale per dof row, in the pair-interleaved layout k_spmv_lp<FMT 2> reads:
-// 4 lanes per block row, lane r owns dof row 4*row + r.  Block j of a row (j = k - rowptr[row]) that has a partner
-// (j ^ 1 within the row) lands in pair j >> 1, half j & 1; an odd last block keeps the plain position.
-__global__ __launch_bounds__(256) void k_cvt_h16(int32_t n_rows, const int32_t* __restrict__ rowptr,
-                                                 const double* __restrict__ vals, uint2* __restrict__ out,
-                                                 float* __restrict__ scale) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = gid >> 2;
-    const int r = (int)(gid & 3);
+// k_lp_copies16: the fp16 copies of a level in ONE pass over its fp64 operator (round 3): the copy of A the smoother reads -- one
+// fp32 scale per dof row (the row's largest |entry|), values pair-interleaved as k_spmv_lp<FMT 2> wants them: 4 lanes per block
+// row, lane r owns dof row 4*row + r; block j of a row that has a partner (j ^ 1 within the row) lands in pair j >> 1, half j & 1,
+// an odd last block keeps the plain position -- and, if the level has one, the same of M = A P for the fused post-smoothing sweep
+// (M slot (i, J) <- sum of the fine blocks (i, j), j in aggregate J; a Dirichlet dof's unit diagonal (:74) taken out where the
+// row's own node is in J).  Until round 3 two kernels (k_cvt_h16, k_ap_cvt<2>) read the 2.3 GB fine-level operator once each in
+// latency-bound loops of one block per step (1.4 - 1.5 ms each at 10 M tets = 2 TB/s).  Here a row of up to 16 blocks is requested UP-FRONT into registers (32 16-B loads in flight per lane), its
+// largest |entry| found, the copy of A written (one 16-B store per pair), and M accumulated from the very same registers: slot t of
+// row i sums the blocks whose nibble in ap_nib[i] is t (block j -> bits 4j .. 4j+3; 15 = the column takes no part), in block order
+// = the order of the ap_idx gather list, so that both copies are BITWISE what the two kernels produced (checked in the solver: same
+// V-cycle, same iterates; AMG setup 7.6 -> 5.7 ms at 10 M tets).  The accumulators of the <= 8
+// M slots of a row live in LDS, 32 B per lane and slot, private to the lane (indexable registers; no barrier).  Rows of more than
+// 16 blocks or more than 8 slots (ap_nib = ~0: coarse levels, unstructured meshes) take the one-block-per-step loops.
+template <int WITH_M>
+__global__ __launch_bounds__(128) void k_lp_copies16(int32_t n_rows, const int32_t* __restrict__ rowptr,
+                                                     const double* __restrict__ vals, uint2* __restrict__ out,
+                                                     float* __restrict__ scale, const int32_t* __restrict__ rowptr_m,
+                                                     const int32_t* __restrict__ colind_m, const int32_t* __restrict__ ap_ptr,
+                                                     const int32_t* __restrict__ ap_idx, const uint64_t* __restrict__ ap_nib,
+                                                     const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
+                                                     uint2* __restrict__ out_m, float* __restrict__ scale_m) {
+    __shared__ double2 acc_lds[WITH_M ? 128 * 8 * 2 : 1];           // [slot][half][lane]
+    const int tid = threadIdx.x;
+    const int64_t row = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 32 + (tid >> 2);       // each XCD walks one contiguous eighth
+    const int r = tid & 3;
     if (row >= n_rows) return;
     const int32_t s = rowptr[row], e = rowptr[row + 1];
-    double m = 0.0;
-    for (int32_t k = s; k < e; ++k) {
-        const double* a = vals + 16 * (int64_t)k + 4 * r;
-        m = fmax(m, fmax(fmax(fabs(a[0]), fabs(a[1])), fmax(fabs(a[2]), fabs(a[3]))));
-    }
-    const float sc = (float)m;
-    const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
-    scale[4 * row + r] = sc;
     const int32_t cnt = e - s;
-    for (int32_t k = s; k < e; ++k) {
-        const double* a = vals + 16 * (int64_t)k + 4 * r;
-        f16x4_t hv;
-        hv.x = (_Float16)(float)(a[0] * inv); hv.y = (_Float16)(float)(a[1] * inv);
-        hv.z = (_Float16)(float)(a[2] * inv); hv.w = (_Float16)(float)(a[3] * inv);
-        const int32_t j = k - s;
-        const bool paired = (j | 1) < cnt;
-        const int64_t dst = paired ? ((int64_t)s * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)k * 4 + r);
-        out[dst] = *reinterpret_cast<const uint2*>(&hv);
+    constexpr int NB = 16;
+    double2 A[NB][2];
+    const bool in_regs = cnt <= NB;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            A[j][0] = A[j][1] = make_double2(0.0, 0.0);
+            if (j < cnt) {
+                const double2* a = reinterpret_cast<const double2*>(vals + 16 * (int64_t)(s + j) + 4 * r);
+                A[j][0] = ld_stream(a); A[j][1] = ld_stream(a + 1);                     // read once: streaming loads
+            }
+        }
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            m = fmax(m, fmax(fmax(fabs(A[j][0].x), fabs(A[j][0].y)), fmax(fabs(A[j][1].x), fabs(A[j][1].y))));
+        const float sc = (float)m;
+        const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+        scale[4 * row + r] = sc;
+#pragma unroll
+        for (int p = 0; p < NB / 2; ++p) {
+            f16x8_t hv;
+            hv[0] = (_Float16)(float)(A[2 * p][0].x * inv); hv[1] = (_Float16)(float)(A[2 * p][0].y * inv);
+            hv[2] = (_Float16)(float)(A[2 * p][1].x * inv); hv[3] = (_Float16)(float)(A[2 * p][1].y * inv);
+            hv[4] = (_Float16)(float)(A[2 * p + 1][0].x * inv); hv[5] = (_Float16)(float)(A[2 * p + 1][0].y * inv);
+            hv[6] = (_Float16)(float)(A[2 * p + 1][1].x * inv); hv[7] = (_Float16)(float)(A[2 * p + 1][1].y * inv);
+            const uint4 u = *reinterpret_cast<const uint4*>(&hv);
+            if (2 * p + 1 < cnt) *reinterpret_cast<uint4*>(out + ((int64_t)s * 4 + p * 8 + r * 2)) = u;      // a pair: 16 B per lane
+            else if (2 * p < cnt) out[(int64_t)(s + 2 * p) * 4 + r] = make_uint2(u.x, u.y);                  // the odd last block
+        }
+    } else {
+        double m = 0.0;
+        for (int32_t k = s; k < e; ++k) {
+            const double* a = vals + 16 * (int64_t)k + 4 * r;
+            m = fmax(m, fmax(fmax(fabs(a[0]), fabs(a[1])), fmax(fabs(a[2]), fabs(a[3]))));
+        }
+        const float sc = (float)m;
+        const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+        scale[4 * row + r] = sc;
+        for (int32_t k = s; k < e; ++k) {
+            const double* a = vals + 16 * (int64_t)k + 4 * r;
+            f16x4_t hv;
+            hv.x = (_Float16)(float)(a[0] * inv); hv.y = (_Float16)(float)(a[1] * inv);
+            hv.z = (_Float16)(float)(a[2] * inv); hv.w = (_Float16)(float)(a[3] * inv);
+            const int32_t j = k - s;
+            const bool paired = (j | 1) < cnt;
+            const int64_t dst = paired ? ((int64_t)s * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)k * 4 + r);
+            out[dst] = *reinterpret_cast<const uint2*>(&hv);
+        }
+    }
+    if constexpr (WITH_M) {
+        const int32_t sm = rowptr_m[row], em = rowptr_m[row + 1];
+        const int32_t cm = em - sm;
+        const int32_t own = agg[row];
+        const bool fixed = free_mask && !free_mask[4 * row + r];
+        const uint64_t nib = ap_nib[row];
+        if (in_regs && nib != ~0ull) {
+            // accumulator (slot t, half h) of lane tid at acc_lds[(2 t + h) * 128 + tid]: consecutive lanes 16 B apart (a lane-major
+            // layout puts all 64 lanes of a wave on the same banks: measured 2x the kernel time)
+            double2* acc = acc_lds + tid;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t * 128] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int t = (int)((nib >> (4 * j)) & 15);
+                if (j < cnt && t < 8) {
+                    double2 v0 = acc[(2 * t) * 128], v1 = acc[(2 * t + 1) * 128];
+                    v0.x += A[j][0].x; v0.y += A[j][0].y; v1.x += A[j][1].x; v1.y += A[j][1].y;
+                    acc[(2 * t) * 128] = v0; acc[(2 * t + 1) * 128] = v1;
+                }
+            }
+            double m = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < cm) {
+                    if (fixed && colind_m[sm + t] == own) {                    // the unit diagonal of a Dirichlet dof is not part of M
+                        double2 v = acc[(2 * t + (r >> 1)) * 128];
+                        if (r & 1) v.y -= 1.0; else v.x -= 1.0;
+                        acc[(2 * t + (r >> 1)) * 128] = v;
+                    }
+                    const double2 v0 = acc[(2 * t) * 128], v1 = acc[(2 * t + 1) * 128];
+                    m = fmax(m, fmax(fmax(fabs(v0.x), fabs(v0.y)), fmax(fabs(v1.x), fabs(v1.y))));
+                }
+            }
+            const float sc = (float)m;
+            const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+            scale_m[4 * row + r] = sc;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (2 * p >= cm) break;
+                const double2 a0 = acc[(4 * p) * 128], a1 = acc[(4 * p + 1) * 128];
+                f16x8_t hv;
+                hv[0] = (_Float16)(float)(a0.x * inv); hv[1] = (_Float16)(float)(a0.y * inv);
+                hv[2] = (_Float16)(float)(a1.x * inv); hv[3] = (_Float16)(float)(a1.y * inv);
+                if (2 * p + 1 < cm) {
+                    const double2 b0 = acc[(4 * p + 2) * 128], b1 = acc[(4 * p + 3) * 128];
+                    hv[4] = (_Float16)(float)(b0.x * inv); hv[5] = (_Float16)(float)(b0.y * inv);
+                    hv[6] = (_Float16)(float)(b1.x * inv); hv[7] = (_Float16)(float)(b1.y * inv);
+                    *reinterpret_cast<uint4*>(out_m + ((int64_t)sm * 4 + p * 8 + r * 2)) = *reinterpret_cast<const uint4*>(&hv);
+                } else {
+                    const uint4 u = *reinterpret_cast<const uint4*>(&hv);
+                    out_m[(int64_t)(sm + 2 * p) * 4 + r] = make_uint2(u.x, u.y);
+                }
+            }
+        } else {
+            auto slot_sum = [&](int32_t q, double (&v)[4]) {
+                v[0] = v[1] = v[2] = v[3] = 0.0;
+                for (int32_t k = ap_ptr[q]; k < ap_ptr[q + 1]; ++k) {
+                    const double* a = vals + 16 * (int64_t)ap_idx[k] + 4 * r;
+                    v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+                }
+                if (fixed && colind_m[q] == own) v[r] -= 1.0;
+            };
+            double m = 0.0;
+            for (int32_t q = sm; q < em; ++q) {
+                double v[4];
+                slot_sum(q, v);
+                m = fmax(m, fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3]))));
+            }
+            const float sc = (float)m;
+            const double inv = m > 0.0 ? 1.0 / (double)sc : 0.0;
+            scale_m[4 * row + r] = sc;
+            for (int32_t q = sm; q < em; ++q) {
+                double v[4];
+                slot_sum(q, v);
+                f16x4_t hv;
+                hv.x = (_Float16)(float)(v[0] * inv); hv.y = (_Float16)(float)(v[1] * inv);
+                hv.z = (_Float16)(float)(v[2] * inv); hv.w = (_Float16)(float)(v[3] * inv);
+                const int32_t j = q - sm;
+                const bool paired = (j | 1) < cm;
+                const int64_t dst = paired ? ((int64_t)sm * 4 + (int64_t)(j >> 1) * 8 + r * 2 + (j & 1)) : ((int64_t)q * 4 + r);
+                out_m[dst] = *reinterpret_cast<const uint2*>(&hv);
+            }
+        }
     }
 }
+template __global__ void k_lp_copies16<0>(int32_t, const int32_t*, const double*, uint2*, float*, const int32_t*, const int32_t*,
+                                          const int32_t*, const int32_t*, const uint64_t*, const int32_t*, const uint8_t*, uint2*, float*);
+template __global__ void k_lp_copies16<1>(int32_t, const int32_t*, const double*, uint2*, float*, const int32_t*, const int32_t*,
+                                          const int32_t*, const int32_t*, const uint64_t*, const int32_t*, const uint8_t*, uint2*, float*);
 
 __global__ __launch_bounds__(256) void k_cvt_f32(int64_t n, const double* __restrict__ x, float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -2318,6 +2418,21 @@ __global__ __launch_bounds__(256) void k_galerkin(int64_t nnzb_c, const int64_t*
     double2 v0 = make_double2(0.0, 0.0), v1 = v0;
     const int64_t k1 = r_ptr[s + 1];
     int64_t k = r_ptr[s];
+    // 8 fine blocks per step (a fine-level coarse slot gathers ~8): all ids first, then all blocks -- two round trips instead of
+    // one dependent pair per two blocks; the even / odd partial sums keep their order (bitwise the result of the loop below)
+    for (; k + 7 < k1; k += 8) {
+        int32_t f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = r_idx[k + q];
+        double2 a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = ld_stream(reinterpret_cast<const double2*>(vals_f + (int64_t)f[q] * 16) + t);
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            v0.x += a[q].x; v0.y += a[q].y;
+            v1.x += a[q + 1].x; v1.y += a[q + 1].y;
+        }
+    }
     for (; k + 1 < k1; k += 2) {
         const int32_t f0 = r_idx[k], f1 = r_idx[k + 1];
         const double2 a = reinterpret_cast<const double2*>(vals_f + (int64_t)f0 * 16)[t];
