@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(256) void k_ap_cvt32(int32_t n_rows, const int32_t*
 // largest |entry| found, the copy of A written (one 16-B store per pair), and M accumulated from the very same registers: slot t of
 // row i sums the blocks whose nibble in ap_nib[i] is t (block j -> bits 4j .. 4j+3; 15 = the column takes no part), in block order
 // = the order of the ap_idx gather list, so that both copies are BITWISE what the two kernels produced (checked in the solver: same
-// V-cycle, same iterates; AMG setup 7.6 -> 5.7 ms at 10 M tets).  The accumulators of the <= 8
+// V-cycle, same iterates; a setup without spectral estimates 5.3 -> 3.05 ms at 10 M tets, 7.2 -> 4.9 ms on average).  The accumulators of the <= 8
 // M slots of a row live in LDS, 32 B per lane and slot, private to the lane (indexable registers; no barrier).  Rows of more than
 // 16 blocks or more than 8 slots (ap_nib = ~0: coarse levels, unstructured meshes) take the one-block-per-step loops.
 template <int WITH_M>
@@ -1913,7 +1913,7 @@ __global__ __launch_bounds__(128) void k_lp_copies16(int32_t n_rows, const int32
         const uint64_t nib = ap_nib[row];
         if (in_regs && nib != ~0ull) {
             // accumulator (slot t, half h) of lane tid at acc_lds[(2 t + h) * 128 + tid]: consecutive lanes 16 B apart (a lane-major
-            // layout puts all 64 lanes of a wave on the same banks: measured 2x the kernel time)
+            // layout puts all 64 lanes of a wave on the same banks: setup 3.21 instead of 3.05 ms at 10 M tets)
             double2* acc = acc_lds + tid;
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[t * 128] = make_double2(0.0, 0.0);
