@@ -72,7 +72,7 @@ struct Level {
     int32_t* r_idx = nullptr;
     uint8_t* free_mask = nullptr;        // 4*n: 1 where dof takes part in transfer (level 0: !bc), else all 1
     // M = A P of this level for the fused first post-smoothing sweep (k_post_lp): pattern + gather lists (symbolic, once),
-    // values per numeric setup straight into the level's low-precision format (k_ap_cvt)
+    // values per numeric setup straight into the level's low-precision format (k_lp_copies16 / k_ap_cvt32)
     int64_t ap_nnz = 0;
     int32_t *ap_rowptr = nullptr, *ap_colind = nullptr, *ap_ptr = nullptr, *ap_idx = nullptr;
     uint64_t* ap_nib = nullptr;          // per row: nibble j = the row-local M slot of block j (15: none); ~0 = row too long for k_lp_copies16's registers
