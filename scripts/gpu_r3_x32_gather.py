@@ -1,0 +1,18 @@
+"""Round 3 (HARNESS build): would an fp32 shadow of the GATHERED operand speed the fp16 preconditioner passes up?  Timing only: the
+production fp16 residual / Jacobi kernels against the same kernels reading the gathered x blocks as 16 B of fp32 (numbers garbage),
+alternating rounds in one process (sns_bench_variants 4 / 5), 10.1 M-tet Jacobian."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+from stabilized_navier_stokes_flow_fenicsx_amd.solver import FlowProblem, check
+m = M.duct_mesh((300, 75, 75), 4.0)
+P = FlowProblem(m, B.duct_bcs(m), reynolds=200.0)
+U, _ = P.stokes_solve()
+F = P.zeros(); P.jacobian(U, "ns", residual_out=F); P.pc_setup()
+for which, name in ((4, "residual r = b - Ax"), (5, "Jacobi sweep")):
+    for rep in range(2):
+        ms = (C.c_double * 2)()
+        check(P.lib.sns_bench_variants(P.h, which, 6, 20, ms))
+        print(f"fp16 {name}: fp64 gather {1e3 * ms[0]:.1f} us, fp32 gather {1e3 * ms[1]:.1f} us ({100 * (ms[1] / ms[0] - 1):+.1f} %)", flush=True)
+P.close()
