@@ -95,14 +95,19 @@ def self_launch(args, argv):
     timer = threading.Timer(args.launch_timeout, reaper)
     timer.daemon = True
     timer.start()
-    got_json = False
+    held = []
     for line in proc.stdout:                           # rank 0's JSON line (and anything else the workers print)
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            held.append(line)                          # the result line goes out only if the launch as a whole succeeded
+            continue
         sys.stdout.write(line)
         sys.stdout.flush()
-        if line.lstrip().startswith("{") and '"metric"' in line:
-            got_json = True
     rc = proc.wait()
     timer.cancel()
+    got_json = bool(held)
+    for line in held:
+        (sys.stdout if rc == 0 and not killed else sys.stderr).write(line if rc == 0 and not killed else "[bench] result line of a FAILED launch (not reported): " + line)
+    sys.stdout.flush()
     if killed:
         return 124
     if rc == 0 and not got_json:
@@ -146,7 +151,18 @@ if __name__ == "__main__":
               "plain command, or run it under torch.distributed.run with --nproc-per-node N)", file=sys.stderr)
         sys.exit(2)
     if _ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(_ARGS, sys.argv[1:]))
+        _t0 = time.monotonic()
+        _rc = self_launch(_ARGS, sys.argv[1:])
+        # One documented fallback: a first attempt that FAILED FAST (crash, not a hang: the launch
+        # timeout and the 900-s watchdog are not retried) is repeated once with the halo exchange and the operator pass on
+        # one stream (SNS_NO_OVERLAP=1: exchange, then one full pass -- the path the single-GPU tests compare the
+        # two-stream choreography against, bitwise); the result line says so under "launch_fallback".
+        if _rc not in (0, 124) and time.monotonic() - _t0 < 300.0 and not os.environ.get("SNS_NO_OVERLAP"):
+            print(f"[bench] first attempt exited {_rc}: one more attempt with SNS_NO_OVERLAP=1", file=sys.stderr, flush=True)
+            os.environ["SNS_NO_OVERLAP"] = "1"
+            os.environ["SNS_BENCH_FALLBACK"] = f"SNS_NO_OVERLAP=1 after a first attempt that exited {_rc}"
+            _rc = self_launch(_ARGS, sys.argv[1:])
+        sys.exit(_rc)
 
 # the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this before HIP initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -323,8 +339,11 @@ def dry_run(args, cfg, cells, length, world, rank):
     WATCHDOG.tick("collectives")
     if os.environ.get("SNS_DRYRUN_STALL_RANK") == str(rank):      # test hook: a rank that never comes back
         time.sleep(3600)
+    if os.environ.get("SNS_DRYRUN_CRASH_WITH_OVERLAP") and not os.environ.get("SNS_NO_OVERLAP") and rank == world - 1:
+        os._exit(7)                                               # test hook: a rank that dies unless the fallback is on
     out = {"metric": "M-DOF/s (assembly+solve) per Newton iteration", "value": None, "unit": "M-DOF/s", "n_gpus": world,
            "dry_run": True, "transport": "gloo (CPU rehearsal, no HIP)", "rccl_ranks": None, "steps": 0, "warmup": 0,
+           "launch_fallback": os.environ.get("SNS_BENCH_FALLBACK"),
            "config": {"workload": f"BASELINE config {cfg}: {nt} tets, partition + halo plans + one all-reduce only",
                       "parallelism": f"element partition x{world}", "owned_nodes_total": int(t[0]),
                       "boundary_rows_total": int(t[1]), "halo_plans_consistent_ranks": int(t[2]),
@@ -550,7 +569,8 @@ def main():
     out = {
         "metric": "M-DOF/s (assembly+solve) per Newton iteration",
         "value": round(value, 3), "unit": "M-DOF/s", "n_gpus": world, "rccl_ranks": comm["rccl_ranks"],
-        "transport": comm["transport"], "halo_overlap_selfcheck": halo_check, "steps": args.steps, "warmup": args.warmup,
+        "transport": comm["transport"], "halo_overlap_selfcheck": halo_check, "launch_fallback": os.environ.get("SNS_BENCH_FALLBACK"),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "precision_note": ("operator, residuals, Krylov recurrences and reductions in f64; the AMG preconditioner's "

@@ -253,6 +253,21 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert d["n_gpus"] == 3 and d["config"]["halo_plans_consistent_ranks"] == 3 and d["config"]["owned_nodes_total"] == 343
 
 
+def test_bench_repeats_a_crashed_launch_once_without_the_two_stream_overlap():
+    """A first attempt that fails fast is repeated ONCE with SNS_NO_OVERLAP=1 (halo exchange and operator pass on one
+    stream) and the result line says so; a launch that works carries launch_fallback = null."""
+    import json
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"], {"SNS_DRYRUN_CRASH_WITH_OVERLAP": "1"})
+    assert rc == 0, err[-2000:]
+    assert "one more attempt with SNS_NO_OVERLAP=1" in err
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "SNS_NO_OVERLAP=1 after a first attempt that exited" in d["launch_fallback"]
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"])
+    assert rc == 0 and json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])["launch_fallback"] is None
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     rc, out, err = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
     assert rc == 2 and "WORLD_SIZE" in err and out.strip() == ""
