@@ -490,32 +490,10 @@ int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, con
     SNS_TRY(dev_upload(&L.ap_colind, M.colind, h->stream));
     SNS_TRY(dev_upload(&L.ap_ptr, M.ap_ptr, h->stream));
     SNS_TRY(dev_upload(&L.ap_idx, M.ap_idx, h->stream));
-    // the same relation per fine block for k_lp_copies16, which accumulates M from the row it holds in registers
-    std::vector<uint64_t> nib((size_t)n_rows);
-    bool force_generic = false;
 #ifdef SNS_HARNESS
-    force_generic = std::getenv("SNS_AP_GENERIC") != nullptr;      // A/B: every row through the one-block-per-step loops
+    if (std::getenv("SNS_AP_GENERIC")) std::fill(M.nib.begin(), M.nib.end(), ~0ull);      // A/B: every row through the one-block-per-step loops
 #endif
-#pragma omp parallel for schedule(static)
-    for (int32_t i = 0; i < n_rows; ++i) {
-        const int32_t s = fine.rowptr[i], cnt = fine.rowptr[i + 1] - s;
-        const int32_t m0 = M.rowptr[i], cm = M.rowptr[i + 1] - m0;
-        uint64_t v = ~0ull;
-        if (cnt <= 16 && cm <= 8 && !force_generic) {
-            v = 0;
-            for (int32_t j = 0; j < 16; ++j) {
-                uint64_t t = 15;
-                if (j < cnt) {
-                    const int32_t J = agg_all[fine.colind[s + j]];
-                    if (J >= 0)
-                        t = (uint64_t)(std::lower_bound(M.colind.begin() + m0, M.colind.begin() + m0 + cm, J) - (M.colind.begin() + m0));
-                }
-                v |= t << (4 * j);
-            }
-        }
-        nib[i] = v;
-    }
-    SNS_TRY(dev_upload(&L.ap_nib, nib, h->stream));
+    SNS_TRY(dev_upload(&L.ap_nib, M.nib, h->stream));
     return SNS_OK;
 }
 

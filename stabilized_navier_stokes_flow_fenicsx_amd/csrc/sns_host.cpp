@@ -297,6 +297,25 @@ void build_ap_pattern(const HostPattern& F, int32_t n_rows, const std::vector<in
             }
         }
     }
+    // block -> slot nibbles (k_lp_copies16 accumulates M from the row it holds in registers, in block order = gather-list order)
+    M.nib.assign((size_t)n_rows, ~0ull);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < n_rows; ++i) {
+        const int32_t s = F.rowptr[i], cnt = F.rowptr[i + 1] - s;
+        const int32_t m0 = M.rowptr[i], cm = M.rowptr[i + 1] - m0;
+        if (cnt > 16 || cm > 8) continue;
+        const int32_t* cb = M.colind.data() + m0;
+        uint64_t v = 0;
+        for (int32_t j = 0; j < 16; ++j) {
+            uint64_t t = 15;
+            if (j < cnt) {
+                const int32_t J = agg_all[F.colind[s + j]];
+                if (J >= 0) t = (uint64_t)(std::lower_bound(cb, cb + cm, J) - cb);
+            }
+            v |= t << (4 * j);
+        }
+        M.nib[i] = v;
+    }
 }
 
 void build_aggregation_active(const HostPattern& F, int32_t n_active, int max_agg, HostAggregation& A) {

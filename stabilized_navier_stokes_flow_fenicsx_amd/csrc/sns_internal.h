@@ -41,6 +41,8 @@ struct HostAP {                          // pattern of M = A P (fine rows x coar
     std::vector<int32_t> rowptr, colind; // per fine row: the aggregates its columns fall into (sorted)
     std::vector<int32_t> slot_row;       // fine row of each M slot
     std::vector<int32_t> ap_ptr, ap_idx; // M slot -> fine slots summed into it
+    std::vector<uint64_t> nib;           // the same relation per fine block of a row: nibble j = row-local M slot of block j (15: the column
+                                         // takes no part); ~0 = the row has more than 16 blocks or more than 8 slots (k_lp_copies16's register path)
 };
 void build_ap_pattern(const HostPattern& F, int32_t n_rows, const std::vector<int32_t>& agg_all, HostAP& M);
 

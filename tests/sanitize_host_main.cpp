@@ -47,6 +47,22 @@ int main() {
                     }
                 }
             }
+        // block -> slot nibbles of k_lp_copies16: the inverse of the gather lists wherever the row fits the kernel's registers
+        if ((int32_t)M2.nib.size() != nown) { std::printf("ERROR nib size\n"); return 1; }
+        int64_t in_regs = 0;
+        for (int32_t i = 0; i < nown; ++i) {
+            const int32_t cnt = cur.rowptr[i + 1] - cur.rowptr[i], cm = M2.rowptr[i + 1] - M2.rowptr[i];
+            if (M2.nib[i] == ~0ull) { if (cnt <= 16 && cm <= 8) { std::printf("ERROR nib fallback\n"); return 1; } continue; }
+            if (cnt > 16 || cm > 8) { std::printf("ERROR nib range\n"); return 1; }
+            ++in_regs;
+            for (int32_t j = 0; j < 16; ++j) {
+                const int t = (int)((M2.nib[i] >> (4 * j)) & 15);
+                if (j >= cnt) { if (t != 15) { std::printf("ERROR nib padding\n"); return 1; } continue; }
+                const int32_t J = A.agg[cur.colind[cur.rowptr[i] + j]];
+                if (J < 0 ? t != 15 : (t >= cm || M2.colind[M2.rowptr[i] + t] != J)) { std::printf("ERROR nib slot\n"); return 1; }
+            }
+        }
+        std::printf("level %d: %ld of %d rows fit the one-pass copy kernel's registers\n", l, (long)in_regs, nown);
         std::printf("level %d: A*P pattern %ld slots (%.2f of the level's blocks)\n", l, (long)M2.nnz, (double)M2.nnz / cur.rowptr[nown]);
         cur = A.coarse; nown = nc;
     }
