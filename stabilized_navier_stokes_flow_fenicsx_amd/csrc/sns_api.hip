@@ -1260,6 +1260,24 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
         if (h->opt.amg_nu_l1_post > 0) nu_post = h->opt.amg_nu_l1_post;
     }
 }
+// Does the restriction from level l also do level l + 1's first sweep (k_restrict with dinv32_c)?  Only where that sweep is
+// the plain rank-local w Dc^-1 bc of a smoothed level on its fp32 D^-1 copy: not the dense coarsest level, not the level whose
+// cycle is the all-gather into the replicated tail (nor that tail's first level, whose right-hand side comes from the gather),
+// not a partitioned level (ghost tails, exchanges), not the experimental fine-cycle shapes.
+inline bool restrict_fuses_first(const sns_ctx* h, int l) {
+    const int nl = (int)h->levels.size();
+    const int c = l + 1;
+    if (l < 0 || c + 1 >= nl) return false;
+#ifdef SNS_HARNESS
+    if (std::getenv("SNS_NO_RESTRICT_FUSE")) return false;
+#endif
+    if (h->rep_level > 0 && (c == h->rep_level - 1 || l == h->rep_level - 1)) return false;
+    if (l == 0 && h->opt.amg_fine_cycle != 0) return false;
+    const Level& C = h->levels[c];
+    if (C.xg || C.n != C.n_owned) return false;
+    return lp_format(h, C) != 0 && C.dinv32 != nullptr;
+}
+
 int vcycle(sns_ctx* h, int l, const double* b, double* x);
 // First level (>= 1) small enough that its kernels are launch-bound rather than bandwidth-bound: it and everything
 // below run as one graph.  10 M tets: level 2 (36 k rows; level 1 has 218 k rows = 46 us per sweep); 1 M tets: level 1.
@@ -1290,6 +1308,8 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_f32_matrix);
     sig.push_back(h->opt.amg_fused_post);
     sig.push_back(h->opt.amg_nu_scale_with_size);
+    sig.push_back(h->opt.amg_fine_cycle);
+    sig.push_back(restrict_fuses_first(h, gl - 1) ? 1.0 : 0.0);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
         if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
@@ -1377,7 +1397,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         Level& C = h->levels[1];
         if (h->opt.amg_fine_cycle == 1) {
             hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
-                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, b, C.b);
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, b, C.b, (const float*)nullptr, 0.0, (double*)nullptr);
             SNS_TRY(coarse_cycle(h, 1, C.b, C.x));
             double* tmp = h->pong[0];
             HIP_TRY(hipMemsetAsync(tmp, 0, 4 * (size_t)rows * sizeof(double), h->stream));
@@ -1387,7 +1407,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, x);
             launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, x, L.r, b, 0.0);
             hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
-                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, (const float*)nullptr, 0.0, (double*)nullptr);
             SNS_TRY(coarse_cycle(h, 1, C.b, C.x));
             hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, x);
         }
@@ -1410,8 +1430,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         HIP_TRY(hipMemsetAsync(cur + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(oth + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
     }
-    // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read
-    if (rows > 0) {
+    // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read (already done
+    // by the restriction kernel of the level above where restrict_fuses_first says so)
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1))) {
         if (lp_format(h, L) != 0 && L.dinv32)
             hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, om, cur);
         else
@@ -1437,9 +1458,19 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     }
     Level& C = h->levels[l + 1];
-    if (C.n_owned > 0)
+    if (C.n_owned > 0) {
+        // the restriction also does the next level's first sweep (z = w Dc^-1 bc into the buffer that level starts from)
+        const float* dc = nullptr;
+        double* zc = nullptr;
+        if (restrict_fuses_first(h, l)) {
+            int cpre = 1, cpost = 1;
+            level_sweeps(h, l + 1, cpre, cpost);
+            dc = C.dinv32;
+            zc = ((cpre - 1 + cpost) & 1) ? h->pong[l + 1] : C.x;
+        }
         hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
-                           C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b);
+                           C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, dc, C.omega, zc);
+    }
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     int s_first = 0;
     // Fused coarse-grid correction + first post-smoothing sweep (k_post_lp): z = (cur + P xc) + om Dinv (r - M xc) with

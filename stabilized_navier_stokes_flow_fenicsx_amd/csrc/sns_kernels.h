@@ -91,7 +91,7 @@ __global__ void k_multi_axpy8(int64_t n, int nv, const double* V, int64_t ldv, c
                               double* w, double* partial);
 __global__ void k_scale_copy(int64_t n, double a, const double* x, double* y);
 __global__ void k_restrict(int32_t nc, const int32_t* m_ptr, const int32_t* m_idx, const uint8_t* free_mask,
-                           const double* r, double* bc);
+                           const double* r, double* bc, const float* dinv32_c, double omega_c, double* z_c);
 __global__ void k_prolong_add(int32_t n, const int32_t* agg, const uint8_t* free_mask, const double* xc, double* x);
 __global__ void k_galerkin(int64_t nnzb_c, const int64_t* r_ptr, const int32_t* r_idx, const double* vals_f,
                            const int32_t* slot_row_c, const int32_t* colind_c, const uint8_t* fixed_c,

@@ -2320,14 +2320,19 @@ __global__ __launch_bounds__(256) void k_scale_copy(int64_t n, double a, const d
 // AMG kernels (plain aggregation, 4 dofs per aggregate)
 // ============================================================================
 // bc[I] = sum_{i in I} free_i * r[i]     (restriction = P0^T, gather => deterministic)
+// With dinv32_c the kernel also does the coarse level's FIRST smoothing sweep from a zero guess, z = omega_c Dc^-1 bc (what
+// k_bjacobi32 would do in a launch of its own right after: the four components of bc sit in the four lanes of the quad; same
+// expression, bitwise the same z) -- one dependent launch less per level and cycle.
 __global__ __launch_bounds__(256) void k_restrict(int32_t nc, const int32_t* __restrict__ m_ptr,
                                                   const int32_t* __restrict__ m_idx,
                                                   const uint8_t* __restrict__ free_mask,
-                                                  const double* __restrict__ r, double* __restrict__ bc) {
+                                                  const double* __restrict__ r, double* __restrict__ bc,
+                                                  const float* __restrict__ dinv32_c, double omega_c,
+                                                  double* __restrict__ z_c) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t I = gid >> 2;
     const int c = (int)(gid & 3);
-    if (I >= nc) return;
+    if (I >= nc) return;                               // whole quads leave together (nc * 4 threads carry work)
     double s = 0.0;
     const int32_t k0 = m_ptr[I], k1 = m_ptr[I + 1];
     int32_t k = k0;
@@ -2360,6 +2365,11 @@ __global__ __launch_bounds__(256) void k_restrict(int32_t nc, const int32_t* __r
         for (int q = 0; q < 8; ++q) s += v[q];
     }
     bc[4 * I + c] = s;
+    if (dinv32_c) {
+        const float4 D = *reinterpret_cast<const float4*>(dinv32_c + 16 * I + 4 * c);
+        const double s0 = quad_bcast<0>(s), s1 = quad_bcast<1>(s), s2 = quad_bcast<2>(s), s3 = quad_bcast<3>(s);
+        z_c[4 * I + c] = omega_c * ((double)D.x * s0 + (double)D.y * s1 + (double)D.z * s2 + (double)D.w * s3);
+    }
 }
 __global__ __launch_bounds__(256) void k_prolong_add(int32_t n, const int32_t* __restrict__ agg,
                                                      const uint8_t* __restrict__ free_mask,
