@@ -74,6 +74,7 @@ struct sns_ctx {
     int dim = 3;
     int32_t n = 0, n_owned = 0;
     int64_t n_global_fine = 0;                   // fine-level rows over all ranks (set when the hierarchy is built)
+    int64_t n_global_l1 = 0;                     // level-1 rows over all ranks (the sweep schedule must be the same on every rank)
     int64_t E = 0;
     int32_t* tets = nullptr;
     double* pts = nullptr;
@@ -640,6 +641,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         double ng[1] = {(double)h->n_owned};
         SNS_TRY(global_sum(h, ng, 1));
         h->n_global_fine = (int64_t)ng[0];
+        h->n_global_l1 = 0;
     }
     h->ghost_gid.assign(1, {});
     h->ghost_own.assign(1, {});
@@ -667,6 +669,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         double prog[2] = {(double)n_owned, (double)nc_owned};
         SNS_TRY(global_sum(h, prog, 2));
         if (prog[1] >= prog[0] || prog[1] == 0.0) break;      // no progress anywhere
+        if (l == 0) h->n_global_l1 = (int64_t)prog[1];
         int32_t nc_total = nc_owned;
         Plan cplan;
         std::vector<int32_t> g_own, g_gid;                     // ghost coarse nodes: owner rank, owner-local id
@@ -994,8 +997,8 @@ inline int level_nu(const sns_ctx* h, int l) {
         // body-centred Delaunay channel, 7 levels) 71 -> 58 iterations per Newton step and 145-148 -> 131-134 ms, where
         // the structured 10 M-tet duct (7 levels as well) pays +3 % for 43.5 -> 43.0 (scripts/gpu_r3_tierA.py)
         const int nlev = (int)h->levels.size() - (h->rep_level > 0 ? 1 : 0);
-        const bool small_aggregates = h->levels.size() > 1 && h->levels[1].n_owned > 0
-                                      && (double)h->levels[0].n_owned < 6.0 * h->levels[1].n_owned;
+        // (global counts: every rank must arrive at the same schedule -- levels with exchanged sweeps are collective)
+        const bool small_aggregates = h->n_global_l1 > 0 && (double)h->n_global_fine < 6.0 * (double)h->n_global_l1;
         if (h->n_global_fine >= 20000000) { add_l2 = 6; add_deep = 10; }       // 192 M tets: 63 / 71 -> 55 / 66, -10 % time
         else if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
         else if (h->n_global_fine >= 2500000 || (nlev >= 7 && small_aggregates)) { add_l2 = 2; add_deep = 2; }
