@@ -979,7 +979,11 @@ int get_vec(sns_ctx* h, size_t k, double** out);
 // operator the fixed w = 0.9 already diverges at 10 M tets, so w is capped per level at the smoothing-optimal 4/(3 |lambda|max).  (Measured cliff on the coarse
 // levels of the 10 M-tet Jacobian: w = 0.80 converges in 45 iterations, w >= 0.82 overflows, although the
 // dominant mode itself is still damped there -- the offending mode is not the one of largest modulus.)
-inline bool level_sx(const sns_ctx* h, const Level& L) { return L.xg && L.n_owned <= h->opt.amg_sweep_exchange_rows; }
+// (rank-local row count: with the option on, a level's ranks must all fall on the same side of the threshold -- the slab / RCB
+// partitions are balanced to a few rows; off (0, the default) no rank ever takes this path, empty ranks included)
+inline bool level_sx(const sns_ctx* h, const Level& L) {
+    return L.xg && h->opt.amg_sweep_exchange_rows > 0 && L.n_owned <= h->opt.amg_sweep_exchange_rows;
+}
 // sweeps per level: the fine level is the expensive one (1 sweep); level 1 and 2 are cheap and are where
 // plain aggregation needs the smoothing (4 and 6); levels >= 3 are launch-bound (2).  Measured on the
 // 10 M-tet Jacobian: (1,4,6,2) 40-42 its / 180-186 ms; (1,4,4,4) 45 / 204; (2,2,2,2) 54 / 323.
