@@ -1274,7 +1274,31 @@ __global__ __launch_bounds__(256) void k_gather_residual(int32_t n_rows, const i
     const int c = (int)(gid & 3);
     if (i >= n_rows) return;
     double s = 0.0;
-    for (int64_t k = nt_ptr[i]; k < nt_ptr[i + 1]; ++k) s += Fe[(int64_t)nt_idx[k] * 4 + c];
+    // ~24 incident tets per node: 8 ids first, then their 8 entries (two round trips per 8 instead of a dependent pair per
+    // tet); summed in list order as before
+    const int64_t k1 = nt_ptr[i + 1];
+    int64_t k = nt_ptr[i];
+    for (; k + 7 < k1; k += 8) {
+        int32_t id[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) id[q] = nt_idx[k + q];
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = Fe[(int64_t)id[q] * 4 + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    if (k < k1) {
+        int32_t id[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) id[q] = (k + q < k1) ? nt_idx[k + q] : -1;
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = id[q] >= 0 ? Fe[(int64_t)id[q] * 4 + c] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (id[q] >= 0) s += v[q];
+    }
     const int64_t dof = 4 * i + c;
     if (bc_mask[dof]) s = (w ? w[dof] : 0.0) - bc_val[dof];
     F[dof] = s;
