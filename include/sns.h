@@ -62,6 +62,9 @@ typedef struct sns_ctx* sns_handle;
 #define SNS_KSP_DIVERGED_ITS         -3
 #define SNS_KSP_DIVERGED_BREAKDOWN   -5
 #define SNS_KSP_DIVERGED_NANORINF    -9
+/* not a PETSc reason and never the final reason of a solve: what sns_get_counters reports (out[6]) for a FIRST attempt that was
+ * ended by the stagnation watch of amg_retry_damping and then retried */
+#define SNS_KSP_STALLED              -100
 #define SNS_SNES_CONVERGED_FNORM_ABS        2
 #define SNS_SNES_CONVERGED_FNORM_RELATIVE   3
 #define SNS_SNES_CONVERGED_SNORM_RELATIVE   4
@@ -130,9 +133,11 @@ typedef struct {
     int    amg_retry_damping; /* 1 (default): a Krylov solve that ends in BREAKDOWN or NANORINF under SNS_PC_AMG is retried
                                once from the same guess with every level's block-Jacobi damping scaled by 0.7 (see
                                sns_krylov_solve); 0: the failed reason is reported and that is it, as PETSc does */
-    int    amg_retry_stall_its; /* with amg_retry_damping: the first BiCGStab attempt also counts as broken down when its best
-                               residual norm has not halved for this many iterations (100; 0 = breakdown / NaN only).
-                               An over-relaxed smoother makes BiCGStab stagnate far more often than break down outright */
+    int    amg_retry_stall_its; /* with amg_retry_damping: the first BiCGStab attempt is also ended (SNS_KSP_STALLED) and retried when
+                               it STAGNATES: no new best residual norm at all for this many iterations, or a best residual
+                               still >= the initial one after this many (100; 0 = breakdown / NaN only).  A solve that converges
+                               slowly keeps setting new bests and is never touched.  An over-relaxed smoother makes BiCGStab
+                               stagnate far more often than break down outright */
     int    halo_overlap;    /* multi-GPU: 1 (default) = level-0 passes compute their interior rows on a second stream while the
                                halo exchange is in flight and the boundary rows after it; 0 = exchange, then one full pass
                                (same arithmetic per row, bitwise the same result).  The environment variable
@@ -148,11 +153,40 @@ typedef struct {
                                one row in six, i.e. an unstructured mesh -- amg_nu_l2 + 2 and amg_nu_deep + 2, from 8 M rows + 4 and + 6, from 20 M rows + 6
                                and + 10 (81 M tets on one GPU: 73 / 82 -> 53 / 57 BiCGStab iterations per Newton step, -25 % time;
                                192 M tets: 95 / 108 -> 55 / 66).  0 = the counts as given */
+    int    amg_dense_rows;  /* (round 4) the first AMG level >= 1 with at most this many block rows (512 = 2048 dofs by default; a
+                               partitioned handle: the first such level of its replicated tail) ends the hierarchy and is solved
+                               EXACTLY by one matvec with its explicit inverse (fp32 storage, fp64 accumulation), rebuilt at every
+                               numeric setup by a blocked Gauss-Jordan elimination on the fp64 matrix cores (csrc/sns_dense.hip,
+                               2 N^3 flops, < 1 ms at N = 2048): one launch instead of the ~15 dependent latency-bound launches
+                               of the deepest levels of the V-cycle.  Fixed when the hierarchy is built, like amg_coarse_size.
+                               0 = coarsen down to amg_coarse_size nodes as in rounds 1-3 */
+    int    amg_block_smooth; /* (round 4) 1 (default): the smoothed levels >= 1 use AGGREGATE-block Jacobi -- the dense block of the
+                               <= 8 nodes (32 dofs) that form one node of the next level, inverted at every numeric setup, in place
+                               of the 4 x 4 nodal block: x <- x + w B^-1 (b - A x), one launch per sweep like before and worth about
+                               two point-block sweeps, so the levels run the shorter schedule below (csrc/sns_block.hip).  2: the
+                               fine level as well (4 KiB of inverse per aggregate).  0: nodal blocks everywhere (rounds 1-3).
+                               Needs amg_f32_matrix != 0 and amg_agg_size <= 8; levels where it does not apply keep the nodal
+                               blocks and their sweep counts.  Fixed when the hierarchy is built */
+    int    amg_bnu_l1;      /* sweeps after the coarse-grid correction on level 1 under amg_block_smooth (3; one sweep before it);
+                               a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*) */
+    int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (3) */
+    int    amg_bnu_deep;    /* ... and on levels >= 3 (1).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
+    int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank (65536): there a sweep is a
+                               latency-bound launch whatever it reads, and halving the sweeps halves the time; on a larger level
+                               the sweep is bandwidth-bound and the 4 KiB of inverse per aggregate cost half a pass again (10 M-tet
+                               duct, level 1 = 218 k rows: 1 + 3 block sweeps = +9 % iterations for no gain per iteration) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
 const char* sns_last_error(void);
 const char* sns_version(void);
+/* ABI guard (round 4): the library's SNS_ABI_VERSION and sizeof(sns_options).  sns_options grows at its END between rounds
+ * and the fixed-size out-arrays of the getters below have grown (sns_get_counters / sns_get_kernel_times: 4 -> 8 entries in
+ * round 3), so a binding built against an older header would pass short buffers: bindings compare both numbers with the
+ * header they were written against before making any other call (the ctypes mirror does, _lib.py) and refuse on a mismatch. */
+#define SNS_ABI_VERSION 4
+int sns_abi_version(void);
+int64_t sns_options_size(void);
 
 /* ---- setup: replaces gmshio.model_to_mesh + functionspace + create_matrix +
  *      locate_dofs_topological/dirichletbc (:111,:127-147,:271-272) ----------
@@ -229,8 +263,8 @@ int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
 /* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
  * guess on entry.  rnorm = 2-norm of the TRUE residual b - A x at exit.  With
  * amg_retry_damping (default on) a solve that ends in DIVERGED_BREAKDOWN or
- * DIVERGED_NANORINF (or, BiCGStab, stagnates for amg_retry_stall_its iterations: reported
- * as a breakdown) under SNS_PC_AMG is retried ONCE from the same guess with every
+ * DIVERGED_NANORINF (or, BiCGStab, stagnates for amg_retry_stall_its iterations: first-attempt
+ * reason SNS_KSP_STALLED) under SNS_PC_AMG is retried ONCE from the same guess with every
  * level's block-Jacobi damping scaled by 0.7; the factor stays until the next
  * sns_set_options.  *its then counts both attempts (<= 2 ksp_max_it), *reason is the
  * last attempt's, the first attempt's is out[6] of sns_get_counters.  Running out of
@@ -280,6 +314,10 @@ int sns_comm_info(sns_handle h, int32_t out[4]);
  * partitioned handle counts its replicated tail copy), per level the rows this rank solves for, the 4x4 blocks of its
  * operator, the sweeps per half cycle level_nu gives it (after amg_nu_scale_with_size) and the block-Jacobi damping in use */
 int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t blocks[16], int32_t sweeps[16], double omega[16]);
+/* the dense coarsest-level solver on its own (tests): Ainv_dev <- inverse of the N x N row-major fp64 matrix A_dev by the blocked
+ * Gauss-Jordan elimination of csrc/sns_dense.hip (64 x 64 blocks, v_mfma_f64_16x16x4_f64 rank-64 updates, NO pivoting: meant for
+ * matrices whose symmetric part is positive definite, like the level operators).  SNS_E_STATE on a zero / non-finite pivot. */
+int sns_dense_inverse(int device, int32_t N, const double* A_dev, double* Ainv_dev);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot,

@@ -433,6 +433,13 @@ static double dotp(int64_t n, const double* a, const double* b) {
     return s;
 }
 
+/* What the last orc_solve saw at its exit (test / bench infrastructure, one solve at a time):
+ * [0] the value its stopping test ran on (TFQMR: the quasi-residual bound tau*sqrt(m+1), which is what PETSc's tfqmr tests;
+ *     BiCGStab: the recurrence residual), [1] 1 if that value met max(rtol*||b||, atol) (= PETSc would report CONVERGED_RTOL),
+ * [2] the TRUE residual ||b - A x|| of the returned iterate, [3] ||b||. */
+static double g_last_info[4] = {0, 0, 0, 0};
+void orc_last_solve_info(double out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_last_info[i]; }
+
 /* KSPSolve: method 0 = BiCGStab (bcgs), 1 = TFQMR (tfqmr); right preconditioning; x holds the initial guess.
  * reason: PETSc numbering (2 rtol, 3 atol, -3 its, -5 breakdown). */
 int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const double* vals, const double* b, double* x,
@@ -451,6 +458,7 @@ int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const dou
     const double tol = fmax(rtol * bn, atol);
     int its = 0, reason = 0;
     if (rn <= tol) reason = rn <= atol ? 3 : 2;
+    g_last_info[0] = rn; g_last_info[1] = reason ? 1.0 : 0.0; g_last_info[2] = rn; g_last_info[3] = bn;
     if (!reason && method == 0) {
         memcpy(rh, r, (size_t)N * sizeof(double));
         double rho = 1, alpha = 1, omega = 1;
@@ -478,6 +486,11 @@ int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const dou
             if (omega == 0.0) { reason = -5; break; }
         }
         if (!reason) { reason = -3; its = maxit; }
+        g_last_info[0] = rn; g_last_info[1] = reason > 0 ? 1.0 : 0.0;
+        orc_spmv(n, rowptr, colind, vals, x, w1);
+        double s2 = 0.0;
+        for (int64_t i = 0; i < N; ++i) { const double e = b[i] - w1[i]; s2 += e * e; }
+        g_last_info[2] = sqrt(s2);
     } else if (!reason) {
         /* TFQMR (Freund 1993) on B = A M^-1;  xhat accumulates in the preconditioned space */
         double *w = w1, *y1 = p, *y2 = s, *u1 = v, *u2 = t, *d = ph, *vv = sh, *xh = w2, *rt = rh;
@@ -526,11 +539,13 @@ int orc_solve(int32_t n, const int32_t* rowptr, const int32_t* colind, const dou
         pc_apply(&P, xh, tmp);
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < N; ++i) x[i] += tmp[i];
+        g_last_info[0] = rn; g_last_info[1] = done ? 1.0 : 0.0;
         /* true residual decides */
         orc_spmv(n, rowptr, colind, vals, x, tmp);
         double s2 = 0.0;
         for (int64_t i = 0; i < N; ++i) { const double e = b[i] - tmp[i]; s2 += e * e; }
         rn = sqrt(s2);
+        g_last_info[2] = rn;
         if (!reason) reason = done ? (rn <= 10.0 * tol ? 2 : -3) : -3;
         if (its > maxit) its = maxit;
         free(tmp);

@@ -89,3 +89,12 @@ def solve(n, rowptr, colind, vals, b, x0=None, method="tfqmr", pc="ilu0", nblock
                   C.c_int(nblocks or num_threads()), C.c_double(rtol), C.c_double(atol), C.c_int(maxit),
                   C.byref(its), C.byref(reason), C.byref(rn))
     return x, its.value, reason.value, rn.value
+
+
+def last_solve_info():
+    """What the last `solve` saw at its exit: dict(tested = the value its stopping test ran on (tfqmr: PETSc's quasi-residual
+    bound tau*sqrt(m+1)), petsc_criterion_met, true_residual = ||b - A x||, bnorm)."""
+    lib = load()
+    out = (C.c_double * 4)()
+    lib.orc_last_solve_info(out)
+    return {"tested": out[0], "petsc_criterion_met": bool(out[1]), "true_residual": out[2], "bnorm": out[3]}

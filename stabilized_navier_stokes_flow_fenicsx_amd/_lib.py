@@ -40,6 +40,12 @@ class SnsOptions(C.Structure):
         ("halo_overlap", C.c_int),
         ("amg_fused_post", C.c_int),
         ("amg_nu_scale_with_size", C.c_int),
+        ("amg_dense_rows", C.c_int),
+        ("amg_block_smooth", C.c_int),
+        ("amg_bnu_l1", C.c_int),
+        ("amg_bnu_l2", C.c_int),
+        ("amg_bnu_deep", C.c_int),
+        ("amg_block_max_rows", C.c_int),
     ]
 
 
@@ -50,6 +56,7 @@ class SnsTimings(C.Structure):
 
 
 # constants of sns.h
+ABI_VERSION = 4                          # SNS_ABI_VERSION of the header this mirror was written against
 FORM_STOKES, FORM_NS = 0, 1
 KSP_BICGSTAB, KSP_FGMRES, KSP_TFQMR = 0, 1, 2
 PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2
@@ -64,6 +71,8 @@ _SIGNATURES = [
     ("sns_default_options", None, [C.POINTER(SnsOptions)]),
     ("sns_last_error", C.c_char_p, []),
     ("sns_version", C.c_char_p, []),
+    ("sns_abi_version", C.c_int, []),
+    ("sns_options_size", C.c_int64, []),
     ("sns_create", C.c_int, [C.POINTER(_H), C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int, C.POINTER(SnsOptions)]),
     ("sns_create_2d", C.c_int, [C.POINTER(_H), C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int, C.POINTER(SnsOptions)]),
     ("sns_destroy", C.c_int, [_H]),
@@ -94,6 +103,7 @@ _SIGNATURES = [
     ("sns_get_counters", C.c_int, [_H, C.POINTER(C.c_int64)]),
     ("sns_comm_info", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("sns_get_hierarchy", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    ("sns_dense_inverse", C.c_int, [C.c_int, C.c_int32, _P, _P]),
     ("sns_reset_timings", C.c_int, [_H]),
     ("sns_time_kernels", C.c_int, [_H, C.c_int]),
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -123,6 +133,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # ABI guard: sns_options grows at its end and the getters' out-arrays have grown between rounds; a mirror of another header
+    # would hand the library short buffers, so refuse before any other call
+    if lib.sns_abi_version() != ABI_VERSION or lib.sns_options_size() != C.sizeof(SnsOptions):
+        raise ImportError(f"{LIB_PATH}: ABI {lib.sns_abi_version()} / sizeof(sns_options) {lib.sns_options_size()} does not match "
+                          f"this binding ({ABI_VERSION} / {C.sizeof(SnsOptions)}): rebuild the library or update _lib.py")
     if hasattr(lib, "sns_bench_variants"):           # experiment build only (make HARNESS=1, csrc/sns_harness.h)
         lib.sns_bench_variants.restype = C.c_int
         lib.sns_bench_variants.argtypes = [_H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]

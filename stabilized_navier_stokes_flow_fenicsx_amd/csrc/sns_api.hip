@@ -222,6 +222,31 @@ int allreduce(sns_ctx* h, double* buf_dev, int count) {
     if (h->comm && h->comm->active()) ++h->ctr_allreduce;
     return comm_allreduce_sum(h->comm.get(), buf_dev, count, h->stream);
 }
+int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev);
+// BiCGStab's two reductions with the scalar update they feed (WHICH 1: alpha, 2: omega & co, k_reduce_final_bicg): without a
+// communicator the last reduction stage and the update are one launch; with one, the all-reduce sits between them
+template <int WHICH>
+int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
+    constexpr int NRED = WHICH == 1 ? 1 : 5;
+    if (h->comm && h->comm->active()) {
+        SNS_TRY(reduce_to(h, nblocks, NRED, red));
+        if (WHICH == 1) hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
+        else hipLaunchKernelGGL(k_bicg_omega, dim3(1), dim3(64), 0, h->stream, sc, red);
+        return SNS_OK;
+    }
+    const double* src = h->partial;
+    int nb = nblocks;
+    if (nblocks > 8192) {                        // (as reduce_local: 2048-wide chunks on many CUs first)
+        const int nchunks = (nblocks + 2047) / 2048;
+        if (nchunks <= 4096) {
+            hipLaunchKernelGGL(k_reduce_chunks, dim3(nchunks, NRED), dim3(256), 0, h->stream, nblocks, NRED, h->partial, h->partial2);
+            src = h->partial2;
+            nb = nchunks;
+        }
+    }
+    hipLaunchKernelGGL((k_reduce_final_bicg<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc);
+    return SNS_OK;
+}
 int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
     reduce_local(h, nblocks, nred, dst_dev);
     return allreduce(h, dst_dev, nred);
@@ -458,6 +483,43 @@ int host_allgather(sns_ctx* h, const std::vector<double>& mine, std::vector<doub
     return SNS_OK;
 }
 
+// Every link of a halo plan must be posted by BOTH ends with matching counts -- rank a sends s nodes to b <=> b receives s nodes
+// from a, zero included: comm_exchange posts no ncclSend / ncclRecv for an empty direction, so the peer must not post the matching
+// call either.  An asymmetric plan deadlocks RCCL where the team transport only reports an error, so every level's plan is checked
+// when it is made (hierarchy build, collective): one all-gather of 2 * nranks counts per rank, and every rank reaches the same
+// verdict from the same table, i.e. a bad plan ends the run on all ranks instead of hanging some of them.
+int check_plan_symmetry(sns_ctx* h, const Plan& p, int level) {
+    Comm* c = h->comm.get();
+    if (!c || !c->active() || c->nranks <= 1) return SNS_OK;
+    const int nr = c->nranks;
+    std::vector<double> mine((size_t)2 * nr, 0.0), all;
+    bool bad_peer = p.send_ptr.size() != p.nbr.size() + 1 || p.recv_ptr.size() != p.nbr.size() + 1;
+    for (size_t k = 0; k < p.nbr.size() && !bad_peer; ++k) {
+        const int peer = p.nbr[k];
+        if (peer < 0 || peer >= nr || peer == c->rank) { bad_peer = true; break; }
+        mine[(size_t)peer] += (double)(p.send_ptr[k + 1] - p.send_ptr[k]);
+        mine[(size_t)nr + peer] += (double)(p.recv_ptr[k + 1] - p.recv_ptr[k]);
+    }
+    if (bad_peer) mine[(size_t)c->rank] = -1.0;                 // (a rank never sends to itself: the slot doubles as the error flag)
+    SNS_TRY(host_allgather(h, mine, all));
+    for (int a = 0; a < nr; ++a) {
+        if (all[(size_t)a * 2 * nr + a] != 0.0) {
+            set_error("halo plan of level " + std::to_string(level) + ": rank " + std::to_string(a) + " lists an invalid neighbour");
+            return SNS_E_COMM;
+        }
+        for (int b = 0; b < nr; ++b) {
+            const double sent = all[(size_t)a * 2 * nr + b], expected = all[(size_t)b * 2 * nr + nr + a];
+            if (sent != expected) {
+                set_error("halo plan of level " + std::to_string(level) + " is asymmetric: rank " + std::to_string(a) + " sends " +
+                          std::to_string((long long)sent) + " nodes to rank " + std::to_string(b) + ", which expects " +
+                          std::to_string((long long)expected));
+                return SNS_E_COMM;
+            }
+        }
+    }
+    return SNS_OK;
+}
+
 int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg) {
     h->levels.emplace_back();
     h->slot_row.push_back(nullptr);
@@ -466,6 +528,7 @@ int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg
     Level& C = h->levels.back();
     SNS_TRY(upload_pattern(C, P, &h->slot_row.back(), h->stream));
     C.n_owned = n_owned;
+    C.n_global = n_owned;                        // (append_level serves the replicated tail: every rank holds all rows)
     SNS_TRY(alloc_level_vectors(C));
     SNS_TRY(dev_alloc(&h->pong.back(), 4 * (size_t)std::max(1, C.n)));
     HIP_TRY(hipMemset(h->pong.back(), 0, 4 * (size_t)std::max(1, C.n) * sizeof(double)));
@@ -476,9 +539,73 @@ int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg
     return SNS_OK;
 }
 
+// Aggregate-block Jacobi smoother (amg_block_smooth, csrc/sns_block.hip), symbolic part: the member rows of every aggregate of
+// level L padded to 8 slots.  Levels whose aggregates can have more than 8 members (amg_agg_size > 8) keep the nodal blocks.
+int upload_block_rows(sns_ctx* h, int l, Level& L, const std::vector<int32_t>& m_ptr, const std::vector<int32_t>& m_idx,
+                      int32_t nc_owned) {
+    const int mode = h->opt.amg_block_smooth;
+    if (mode <= 0 || (l == 0 && mode < 2) || nc_owned < 0) return SNS_OK;
+    std::vector<int32_t> rows((size_t)8 * std::max(1, nc_owned), -1);
+    for (int32_t G = 0; G < nc_owned; ++G) {
+        const int32_t cnt = m_ptr[(size_t)G + 1] - m_ptr[(size_t)G];
+        if (cnt > 8) return SNS_OK;
+        for (int32_t q = 0; q < cnt; ++q) rows[(size_t)8 * G + q] = m_idx[(size_t)m_ptr[(size_t)G] + q];
+    }
+    L.n_blk = nc_owned;
+    SNS_TRY(dev_upload(&L.blk_rows, rows, h->stream));
+    return SNS_OK;
+}
+// Is level l smoothed with the aggregate blocks?  (options only, no device state: every rank of a partitioned run must answer alike)
+inline bool block_active(const sns_ctx* h, int l) {
+    if (h->opt.amg_block_smooth <= 0 || h->opt.amg_f32_matrix == 0 || h->opt.pc_type != SNS_PC_AMG) return false;
+    if (l < 0 || l + 1 >= (int)h->levels.size()) return false;                 // the coarsest level is solved or point-smoothed
+    const Level& L = h->levels[l];
+    if (!L.blk_rows) return false;
+    if (l == 0 && (h->opt.amg_block_smooth < 2 || L.xg)) return false;
+    if (h->rep_level > 0 && l == h->rep_level - 1) return false;               // only the source of the replicated copy
+    // latency-bound levels only (rows per rank, the same figure on every rank)
+    const bool replicated = h->rep_level > 0 && l >= h->rep_level;
+    const int nr = (h->comm && h->comm->active() && !replicated) ? std::max(1, h->comm->nranks) : 1;
+    if (h->opt.amg_block_max_rows > 0 && L.n_global > (int64_t)h->opt.amg_block_max_rows * nr) return false;
+    return true;
+}
+
+// one smoothing sweep y = x + w S (b - A x) of level l: S = the aggregates' inverse blocks where block_active, else the nodal D^-1
+void launch_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double* x, double* y, const double* b, double omega) {
+    if (block_active(h, l) && L.binv32) {
+        const int32_t ns = 8 * L.n_blk;
+        const unsigned grid = (unsigned)((ns + 63) / 64);
+        if (grid == 0) return;
+        if (lp_format(h, L) == 2)
+            hipLaunchKernelGGL((k_bsweep<2>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                               (const void*)L.vals16, L.scale16, (const float4*)L.binv32, x, y, b, omega);
+        else
+            hipLaunchKernelGGL((k_bsweep<1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                               (const void*)L.vals32, (const float*)nullptr, (const float4*)L.binv32, x, y, b, omega);
+        return;
+    }
+    launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x, y, b, omega);
+}
+// first sweep of a cycle from the zero guess, z = w S b (omega = 1: S b alone, the spectral estimate's operator)
+void launch_first_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double* b, double omega, double* z) {
+    if (rows <= 0) return;
+    const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
+    if (block_active(h, l) && L.binv32) {
+        const int32_t ns = 8 * L.n_blk;
+        hipLaunchKernelGGL(k_bfirst, dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
+                           (const float4*)L.binv32, b, omega, z);
+    } else if (lp_format(h, L) != 0 && L.dinv32) {
+        hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, omega, z);
+    } else {
+        hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, omega, z);
+    }
+}
+
 // symbolic part of M = A P of a level (fused first post-smoothing sweep, k_post_lp): pattern + gather lists -> device
+// (a rank WITHOUT owned rows uploads the empty pattern all the same: whether a level takes the fused post-sweep -- one level-(l+1)
+// exchange -- or the prolongation + level-l halo is decided from these arrays, and every rank must take the same branch)
 int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, const std::vector<int32_t>& agg_all) {
-    if (n_rows <= 0) return SNS_OK;
+    if (n_rows < 0) n_rows = 0;
     HostAP M;
     try {
         build_ap_pattern(fine, n_rows, agg_all, M);
@@ -497,6 +624,27 @@ int upload_ap(sns_ctx* h, Level& L, const HostPattern& fine, int32_t n_rows, con
     SNS_TRY(dev_upload(&L.ap_nib, M.nib, h->stream));
     return SNS_OK;
 }
+
+// The coarsest level's direct solve: <= max(amg_coarse_size, 40) nodes take the one-workgroup inverse with partial pivoting of
+// rounds 1-3, up to amg_dense_rows nodes the blocked Gauss-Jordan inverse on the matrix cores (csrc/sns_dense.hip); a larger
+// last level (amg_max_levels reached) is smoothed.
+int alloc_coarsest_solver(sns_ctx* h, Level& last) {
+    const sns_options& o = h->opt;
+    if (last.n <= std::max(o.amg_coarse_size, 40)) {
+        const size_t N = 4 * (size_t)last.n;
+        SNS_TRY(dev_alloc(&last.dense_inv, N * N));
+        SNS_TRY(dev_alloc(&h->d_piv, N));
+    } else if (last.n <= o.amg_dense_rows) {
+        const int Np = (4 * last.n + 63) / 64 * 64;
+        last.dense_np = Np;
+        SNS_TRY(dev_alloc(&last.dense_gj, (size_t)Np * Np));
+        SNS_TRY(dev_alloc(&last.dense_work, dense_gj_work_doubles(Np)));
+        SNS_TRY(dev_alloc(&last.dense_x32, (size_t)Np * Np));
+    }
+    return SNS_OK;
+}
+// rows at or below which a level >= 1 ends the hierarchy (it is solved directly)
+inline int coarsest_rows(const sns_options& o) { return std::max(o.amg_coarse_size, std::min(o.amg_dense_rows, 4096)); }
 
 // Multi-GPU: from level R on, every rank holds the GLOBAL operator (values all-gathered at every numeric setup)
 // and cycles the rest of the hierarchy redundantly: no exchanges below R, and the smoothing there is the exact
@@ -594,7 +742,7 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
     HostPattern curp = std::move(G);
     int32_t n_own = NG;
     for (int l = h->rep_level; (int)h->levels.size() < o.amg_max_levels + 1; ++l) {
-        if (n_own <= o.amg_coarse_size) break;
+        if (n_own <= coarsest_rows(o)) break;
         std::vector<int32_t> agg;
         int32_t nc = 0;
         aggregate_nodes(curp, n_own, std::min(255, std::max(2, o.amg_agg_size)), agg, nc);
@@ -609,6 +757,7 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
             SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
             SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
             SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+            SNS_TRY(upload_block_rows(h, l, L, A.m_ptr, A.m_idx, nc));
             SNS_TRY(upload_ap(h, L, curp, n_own, A.agg));
         }
         SNS_TRY(append_level(h, A.coarse, nc, false));
@@ -617,12 +766,7 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
         curp = std::move(A.coarse);
         n_own = nc;
     }
-    Level& last = h->levels.back();
-    if (last.n <= std::max(o.amg_coarse_size, 40)) {
-        const size_t N = 4 * (size_t)last.n;
-        SNS_TRY(dev_alloc(&last.dense_inv, N * N));
-        SNS_TRY(dev_alloc(&h->d_piv, N));
-    }
+    SNS_TRY(alloc_coarsest_solver(h, h->levels.back()));
     h->tm.amg_levels = (int)h->levels.size() - 1;
     return SNS_OK;
 }
@@ -642,6 +786,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         SNS_TRY(global_sum(h, ng, 1));
         h->n_global_fine = (int64_t)ng[0];
         h->n_global_l1 = 0;
+        h->levels[0].n_global = h->n_global_fine;
     }
     h->ghost_gid.assign(1, {});
     h->ghost_own.assign(1, {});
@@ -663,6 +808,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         double flag[1] = {n_owned > per_rank_coarse ? 1.0 : 0.0};
         SNS_TRY(global_sum(h, flag, 1));
         if (flag[0] == 0.0) break;
+        if (!dist && l >= 1 && n_owned <= coarsest_rows(o)) break;       // serial: this level is solved directly
         std::vector<int32_t> agg;
         int32_t nc_owned = 0;
         aggregate_nodes(cur, n_owned, std::min(255, std::max(2, o.amg_agg_size)), agg, nc_owned);
@@ -723,6 +869,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         SNS_TRY(dev_upload(&L.m_idx, A.m_idx, h->stream));
         SNS_TRY(dev_upload(&L.r_ptr, A.r_ptr, h->stream));
         SNS_TRY(dev_upload(&L.r_idx, A.r_idx, h->stream));
+        SNS_TRY(upload_block_rows(h, l, L, A.m_ptr, A.m_idx, nc_owned));
         // M = A P for the fused first post-smoothing sweep: every level of a serial hierarchy; in a partitioned one the fine
         // level only (its single post-sweep is the exact global sweep; the distributed coarse levels smooth rank-locally)
         if (!dist || l == 0) SNS_TRY(upload_ap(h, L, cur, n_owned, A.agg));
@@ -734,12 +881,14 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         if (&h->levels[l] != &L) { set_error("internal: level storage moved"); return SNS_E_STATE; }
         SNS_TRY(upload_pattern(C, A.coarse, &h->slot_row.back(), h->stream));
         C.n_owned = nc_owned;
+        C.n_global = (int64_t)prog[1];
         SNS_TRY(alloc_level_vectors(C));
         SNS_TRY(dev_alloc(&h->pong.back(), 4 * (size_t)C.n));
         HIP_TRY(hipMemset(h->pong.back(), 0, 4 * (size_t)C.n * sizeof(double)));
         if (dist) {
             SNS_TRY(dev_alloc(&C.xg, 4 * (size_t)C.n));
             HIP_TRY(hipMemset(C.xg, 0, 4 * (size_t)C.n * sizeof(double)));
+            SNS_TRY(check_plan_symmetry(h, cplan, l + 1));
             SNS_TRY(plan_upload(cplan));
             c->plans.push_back(std::move(cplan));
         }
@@ -757,11 +906,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     Level& last = h->levels.back();
     if (h->levels.size() > 1) {
         if (!dist) {
-            if (last.n <= std::max(o.amg_coarse_size, 40)) {
-                const size_t N = 4 * (size_t)last.n;
-                SNS_TRY(dev_alloc(&last.dense_inv, N * N));
-                SNS_TRY(dev_alloc(&h->d_piv, N));
-            }
+            SNS_TRY(alloc_coarsest_solver(h, last));
         } else {
             // global dense coarsest solve, replicated on every rank: rank r's node i -> padded id r*maxn + i
             std::vector<double> cnt(c->nranks, 0.0);
@@ -1000,12 +1145,23 @@ inline int level_nu(const sns_ctx* h, int l) {
         // its coarse operators are denser -- it gains from the first tier of extra sweeps already: config 4u (5 M-tet
         // body-centred Delaunay channel, 7 levels) 71 -> 58 iterations per Newton step and 145-148 -> 131-134 ms, where
         // the structured 10 M-tet duct (7 levels as well) pays +3 % for 43.5 -> 43.0 (scripts/gpu_r3_tierA.py)
-        const int nlev = (int)h->levels.size() - (h->rep_level > 0 ? 1 : 0);
+        // (depth as rounds 1-3 counted it: a hierarchy that ends in the dense level of round 4 would have gone on for
+        // ~log5(rows / amg_coarse_size) more levels)
+        int nlev = (int)h->levels.size() - (h->rep_level > 0 ? 1 : 0);
+        if (h->levels.back().dense_gj && h->levels.back().n > h->opt.amg_coarse_size)
+            nlev += (int)std::ceil(std::log((double)h->levels.back().n / std::max(1, h->opt.amg_coarse_size)) / std::log(5.0));
         // (global counts: every rank must arrive at the same schedule -- levels with exchanged sweeps are collective)
         const bool small_aggregates = h->n_global_l1 > 0 && (double)h->n_global_fine < 6.0 * (double)h->n_global_l1;
         if (h->n_global_fine >= 20000000) { add_l2 = 6; add_deep = 10; }       // 192 M tets: 63 / 71 -> 55 / 66, -10 % time
         else if (h->n_global_fine >= 8000000) { add_l2 = 4; add_deep = 6; }
         else if (h->n_global_fine >= 2500000 || (nlev >= 7 && small_aggregates)) { add_l2 = 2; add_deep = 2; }
+    }
+    if (block_active(h, l) && ll >= 1) {
+        // aggregate blocks: one sweep is worth about two nodal-block sweeps (level 1 of a single-GPU handle: 1 + amg_bnu_l1, see
+        // level_sweeps); the size-scaled extra sweeps are halved likewise
+        if (ll >= 3) return std::max(1, h->opt.amg_bnu_deep) + (add_deep + 1) / 2;
+        if (ll == 2) return std::max(1, h->opt.amg_bnu_l2) + (add_l2 + 1) / 2;
+        return std::max(1, h->opt.amg_bnu_l2);
     }
     int nu = std::max(1, h->opt.amg_nu);
     if (ll >= 3 && h->opt.amg_nu_deep > 0) nu = h->opt.amg_nu_deep + add_deep;
@@ -1017,7 +1173,7 @@ inline int level_nu(const sns_ctx* h, int l) {
 // sweep; with several sweeps the ghost values would be frozen while the owned ones move, which measurably hurts
 // the Stokes operator (8 slabs of the 10 M-tet duct: 47 -> 65 iterations) -- so only where nu = 1 (the fine level)
 inline bool level_px(const sns_ctx* h, int l, const Level& L) {
-    return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1;
+    return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1 && !block_active(h, l);
 }
 inline bool uses_ghosts_in_sweeps(const sns_ctx* h, int l, const Level& L) { return level_sx(h, L) || level_px(h, l, L); }
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
@@ -1048,7 +1204,8 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
         if (lp_format(h, L) != 0 && zero) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, x, y, zero, 0.0);
         else launch_spmv<SPMV_AX>(h, L, rows, x, y, nullptr, 0.0, nullptr);
         if (rows > 0) {
-            hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
+            if (block_active(h, l) && L.binv32) launch_first_sweep(h, l, L, rows, y, 1.0, z);      // the smoother's own blocks
+            else hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, y, 1.0, z);
             hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, x, z, h->partial);   // (x.z, z.z)
         }
         if (glob) SNS_TRY(reduce_to(h, g, 2, h->d_scal + 16 + 2 * it));
@@ -1083,7 +1240,7 @@ int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
     // keep x0 intact (it seeds later trials): first sweep x0 -> xa, then ping-pong xa <-> xb
     const bool glob = uses_ghosts_in_sweeps(h, l, L);
     if (glob) SNS_TRY(exchange_level(h, l, x0));
-    launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x0, xa, zero, omega);
+    launch_sweep(h, l, L, rows, x0, xa, zero, omega);
     double* cur = xa;
     double* oth = xb;
     const int sweeps = 6;
@@ -1094,7 +1251,7 @@ int jacobi_growth(sns_ctx* h, int l, double omega, double* growth) {
             else reduce_local(h, g, 2, h->d_scal + 48 + (s == 2 ? 0 : 2));
         }
         if (glob) SNS_TRY(exchange_level(h, l, cur));
-        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, zero, omega);
+        launch_sweep(h, l, L, rows, cur, oth, zero, omega);
         std::swap(cur, oth);
     }
     double v[4];
@@ -1108,6 +1265,7 @@ int pc_setup(sns_ctx* h) {
     if (!h->has_matrix) { set_error("pc_setup before a matrix was assembled"); return SNS_E_STATE; }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     const int nl = (h->opt.pc_type == SNS_PC_AMG) ? (int)h->levels.size() : 1;
+    bool any_block = false;
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
         const int32_t rows = L.n_owned;
@@ -1125,8 +1283,17 @@ int pc_setup(sns_ctx* h) {
         }
         if (rows > 0)
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
+        if (block_active(h, l)) {
+            // the aggregates' inverse diagonal blocks, from the fp64 operator (what the nodal D^-1 is to the point smoother)
+            if (!L.binv32) SNS_TRY(dev_alloc(&L.binv32, (size_t)1024 * std::max(1, L.n_blk)));
+            if (L.n_blk > 0)
+                hipLaunchKernelGGL(k_binv, dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.m_ptr, L.m_idx,
+                                   L.agg, L.rowptr, L.colind, L.vals, (float4*)L.binv32, h->d_sing);
+            any_block = true;
+        }
         L.omega = h->opt.amg_omega * h->damping_backoff;
-        if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
+        const bool direct = (L.dense_inv || L.dense_gj || h->cg_N > 0) && l + 1 == nl && nl > 1;   // solved, not smoothed
+        if (h->opt.pc_type == SNS_PC_AMG && h->opt.amg_f32_matrix && !direct) {
             if (!L.dinv32) SNS_TRY(dev_alloc(&L.dinv32, (size_t)16 * std::max(1, L.n)));
             if (rows > 0)
                 hipLaunchKernelGGL(k_cvt_f32, dim3(vec_grid(16 * (int64_t)rows)), dim3(256), 0, h->stream, 16 * (int64_t)rows,
@@ -1171,7 +1338,7 @@ int pc_setup(sns_ctx* h) {
                                        L.vals32);
             }
         }
-        if (h->opt.pc_type == SNS_PC_AMG && !((L.dense_inv || h->cg_N > 0) && l + 1 == nl)) {
+        if (h->opt.pc_type == SNS_PC_AMG && !direct) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
             double lam = L.lambda_max;
             // (collective when the level's sweeps use exchanged ghost values: every rank takes part, rows or not)
@@ -1226,6 +1393,18 @@ int pc_setup(sns_ctx* h) {
                                h->comm->rank * mr, N, h->cg_rows);
             SNS_TRY(comm_allgather(h->comm.get(), h->cg_rows, h->cg_full, mr * N, h->stream));
             hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(1024), 0, h->stream, N, h->cg_full, h->d_piv, h->d_sing);
+        } else if (L.dense_gj && nl > 1) {
+            // blocked Gauss-Jordan inverse on the fp64 matrix cores, then its fp32 copy for the cycle's matvec
+            const int N = 4 * L.n, Np = L.dense_np;
+            HIP_TRY(hipMemsetAsync(L.dense_gj, 0, (size_t)Np * Np * sizeof(double), h->stream));
+            const int64_t nth = L.nnzb * 16;
+            hipLaunchKernelGGL(k_bsr_to_dense_ld, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.nnzb,
+                               h->slot_row[l], L.colind, L.vals, Np, L.dense_gj);
+            if (Np > N) hipLaunchKernelGGL(k_dense_pad_diag, dim3((Np - N + 255) / 256), dim3(256), 0, h->stream, N, Np, L.dense_gj);
+            dense_gj_inverse(h->stream, Np, L.dense_gj, L.dense_work, h->d_sing);
+            const int64_t nn = (int64_t)Np * Np;
+            hipLaunchKernelGGL(k_dense_to_f32, dim3((unsigned)((nn / 4 + 255) / 256)), dim3(256), 0, h->stream, nn, L.dense_gj,
+                               L.dense_x32);
         } else if (L.dense_inv && nl > 1) {
             const int N = 4 * L.n;
             HIP_TRY(hipMemsetAsync(L.dense_inv, 0, (size_t)N * N * sizeof(double), h->stream));
@@ -1237,12 +1416,23 @@ int pc_setup(sns_ctx* h) {
         }
     }
     ++h->pc_setups;
+    const bool check_sing = nl > 1 && (h->levels[nl - 1].dense_gj != nullptr || any_block);
+    int* h_sing = reinterpret_cast<int*>(h->h_scal + 768);
+    if (check_sing) HIP_TRY(hipMemcpyAsync(h_sing, h->d_sing, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->tm.pc_setup_ms += ms;
     HIP_TRY(hipGetLastError());
+    if (check_sing && *h_sing != 0) {
+        // (the elimination runs without pivoting across its 64 x 64 blocks: see csrc/sns_dense.hip for why that is safe on this
+        // operator class; if it ever is not, say so instead of preconditioning with garbage)
+        HIP_TRY(hipMemset(h->d_sing, 0, sizeof(int)));
+        set_error("AMG setup: a dense inverse (coarsest level or an aggregate block) met a zero or non-finite pivot; set "
+                  "amg_dense_rows = 0 / amg_block_smooth = 0");
+        return SNS_E_STATE;
+    }
     h->pc_ready = true;
     return SNS_OK;
 }
@@ -1259,6 +1449,10 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
         // elsewhere); a partitioned handle keeps nu + nu, its post-sweeps being rank-local (1 + 6 costs 8-11 % more
         // iterations there)
         const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
+        if (block_active(h, l)) {
+            if (!partitioned) { nu_pre = 1; nu_post = std::max(1, h->opt.amg_bnu_l1); }
+            return;
+        }
         if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
             nu_pre = 1;
             nu_post = nu + 2;
@@ -1282,7 +1476,17 @@ inline bool restrict_fuses_first(const sns_ctx* h, int l) {
     if (l == 0 && h->opt.amg_fine_cycle != 0) return false;
     const Level& C = h->levels[c];
     if (C.xg || C.n != C.n_owned) return false;
+    if (block_active(h, c)) return C.binv32 != nullptr;    // k_restrict_blk: restriction in the order of the coarse aggregates
     return lp_format(h, C) != 0 && C.dinv32 != nullptr;
+}
+
+// The buffer a smoothed level's cycle starts from (its first sweep z = w D^-1 b is written there; after
+// nu_pre - 1 + nu_post ping-pong swaps the result must sit in x): the ONE place that knows the parity rule -- vcycle() and the
+// restriction of the level above (which writes that first sweep when restrict_fuses_first says so) both ask here.
+inline double* cycle_start_buffer(sns_ctx* h, int l, double* x) {
+    int nu_pre = 1, nu_post = 1;
+    level_sweeps(h, l, nu_pre, nu_post);
+    return ((nu_pre - 1 + nu_post) & 1) ? h->pong[l] : x;
 }
 
 int vcycle(sns_ctx* h, int l, const double* b, double* x);
@@ -1316,6 +1520,8 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_fused_post);
     sig.push_back(h->opt.amg_nu_scale_with_size);
     sig.push_back(h->opt.amg_fine_cycle);
+    sig.push_back(h->opt.amg_block_smooth); sig.push_back(h->opt.amg_bnu_l1); sig.push_back(h->opt.amg_bnu_l2);
+    sig.push_back(h->opt.amg_bnu_deep); sig.push_back(h->opt.amg_block_max_rows);
     sig.push_back(restrict_fuses_first(h, gl - 1) ? 1.0 : 0.0);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
@@ -1387,6 +1593,11 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             hipLaunchKernelGGL(k_dense_matvec, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_inv, b, x, N);
             return SNS_OK;
         }
+        if (L.dense_x32) {
+            const int N = 4 * L.n;
+            hipLaunchKernelGGL(k_dense_matvec32, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_np, L.dense_x32, b, x);
+            return SNS_OK;
+        }
         // coarsest level too large for the dense solve: a fixed number of Jacobi sweeps (still a linear operator)
         double* cur = x;
         double* oth = h->pong[l];
@@ -1423,9 +1634,8 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     const int nu = level_nu(h, l);
     int nu_pre = nu, nu_post = nu;
     level_sweeps(h, l, nu_pre, nu_post);
-    const int nswaps = nu_pre - 1 + nu_post;
-    double* cur = (nswaps & 1) ? h->pong[l] : x;
-    double* oth = (nswaps & 1) ? x : h->pong[l];
+    double* cur = cycle_start_buffer(h, l, x);
+    double* oth = (cur == x) ? h->pong[l] : x;
     // distributed: on levels with few rows per rank the sweeps see the neighbours' current iterate (one small
     // exchange per sweep); on the big levels they stay rank-local (ghost values zero) and only the residual is exact
     const bool sx = level_sx(h, L);
@@ -1439,15 +1649,10 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     }
     // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read (already done
     // by the restriction kernel of the level above where restrict_fuses_first says so)
-    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1))) {
-        if (lp_format(h, L) != 0 && L.dinv32)
-            hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, om, cur);
-        else
-            hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
-    }
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1))) launch_first_sweep(h, l, L, rows, b, om, cur);
     for (int s = 1; s < nu_pre; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
-        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
+        launch_sweep(h, l, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
     if (sx) {
@@ -1469,14 +1674,19 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         // the restriction also does the next level's first sweep (z = w Dc^-1 bc into the buffer that level starts from)
         const float* dc = nullptr;
         double* zc = nullptr;
-        if (restrict_fuses_first(h, l)) {
-            int cpre = 1, cpost = 1;
-            level_sweeps(h, l + 1, cpre, cpost);
+        const bool fuse = restrict_fuses_first(h, l);
+        if (fuse) {
             dc = C.dinv32;
-            zc = ((cpre - 1 + cpost) & 1) ? h->pong[l + 1] : C.x;
+            zc = cycle_start_buffer(h, l + 1, C.x);          // (coarse_cycle below is called with x = C.x)
         }
-        hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
-                           C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, dc, C.omega, zc);
+        if (fuse && block_active(h, l + 1)) {
+            const int32_t ns = 8 * C.n_blk;
+            hipLaunchKernelGGL(k_restrict_blk, dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows, L.m_ptr,
+                               L.m_idx, L.free_mask, L.r, C.b, (const float4*)C.binv32, C.omega, zc);
+        } else {
+            hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, dc, C.omega, zc);
+        }
     }
     SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
     int s_first = 0;
@@ -1501,7 +1711,18 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             const int grid = (rows + 63) / 64;
             const bool fine = (l == 0);
             if (fine) time_begin(h, 4);
-            if (fmt_l == 2) {
+            if (block_active(h, l) && L.binv32) {
+                const int32_t ns = 8 * L.n_blk;
+                const unsigned gb = (unsigned)((ns + 63) / 64);
+                if (fmt_l == 2)
+                    hipLaunchKernelGGL((k_bpost<2>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals16, L.ap_scale16, (const float4*)L.binv32, xc, cur, L.r, om, L.agg,
+                                       L.free_mask, oth);
+                else
+                    hipLaunchKernelGGL((k_bpost<1>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, (const float4*)L.binv32, xc, cur, L.r, om,
+                                       L.agg, L.free_mask, oth);
+            } else if (fmt_l == 2) {
                 if (fine)
                     hipLaunchKernelGGL((k_post_lp<2, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
                                        L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth);
@@ -1541,7 +1762,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     }
     for (int s = s_first; s < nu_post; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
-        launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
+        launch_sweep(h, l, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
     // cur == x by construction of the start buffer
@@ -1671,11 +1892,11 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             const int32_t rows = h->n_owned;
             const int gs = (rows + 31) / 32;
             SNS_TRY(op_apply_dot(h, ph, v, rhat));        // v = A ph with the fused partial sums of <rhat, v>
-            SNS_TRY(reduce_to(h, 4 * (gs + h->bnd_dot_blocks), 1, red));     // one partial per wave
-            hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
+            SNS_TRY(reduce_bicg<1>(h, 4 * (gs + h->bnd_dot_blocks), red, sc));     // one partial per wave; alpha
             return SNS_OK;
         };
         SNS_TRY(first_half(false));
+        const double rn0 = rn;
         double best_rn = rn;
         int best_it = 0;
         for (its = 1;; ++its) {
@@ -1683,8 +1904,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             SNS_TRY(pc_apply(h, s, sh));
             SNS_TRY(op_apply(h, sh, t));
             hipLaunchKernelGGL(k_bicg_dots5, dim3(g), dim3(256), 0, h->stream, nd, s, t, rhat, h->partial);
-            SNS_TRY(reduce_to(h, g, 5, red));
-            hipLaunchKernelGGL(k_bicg_omega, dim3(1), dim3(64), 0, h->stream, sc, red);
+            SNS_TRY(reduce_bicg<2>(h, g, red, sc));                       // omega, next rho / beta, ||r||^2, flags
             HIP_TRY(hipMemcpyAsync(hpin, sc + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipEventRecord(h->ev_it, h->stream));
             // speculative first half of the next iteration, enqueued BEFORE the host looks at this one's result; its p-update
@@ -1716,11 +1936,16 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             if (flags & 2) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
             if (its >= o.ksp_max_it) { reason = SNS_KSP_DIVERGED_ITS; break; }
             // stagnation watch of the damping-retry feature (stall_window > 0 only on an attempt that can still be retried):
-            // BiCGStab under an over-relaxed smoother often does not break down outright but wanders without ever
-            // improving on its best residual by much (the first Jacobian of a 1.5 M-tet duct at cell Reynolds number 10 crept on
-            // for 641 iterations in 10 % steps); after stall_window iterations without HALVING it the attempt is over
-            if (rn < 0.5 * best_rn) { best_rn = rn; best_it = its; }
-            if (stall_window > 0 && its - best_it >= stall_window) { reason = SNS_KSP_DIVERGED_BREAKDOWN; break; }
+            // BiCGStab under an over-relaxed smoother often does not break down outright but wanders without ever getting
+            // anywhere.  Only REAL stagnation ends the attempt: no new best residual at all for stall_window
+            // iterations, or, after stall_window iterations, a best residual still at or above the initial one.  A solve
+            // that converges slowly -- BiCGStab plateaus on convection-dominated Jacobians -- keeps setting new bests and is
+            // left alone, like PETSc's bcgs would leave it.  The attempt's reason is SNS_KSP_STALLED (not a breakdown).
+            if (rn < best_rn) { best_rn = rn; best_it = its; }
+            if (stall_window > 0 && (its - best_it >= stall_window || (its >= stall_window && best_rn >= rn0))) {
+                reason = SNS_KSP_STALLED;
+                break;
+            }
             if (flags & 4) { reason = SNS_KSP_DIVERGED_BREAKDOWN; ++its; break; }   // rho == 0 stops the NEXT iteration
         }
         // the stopping test runs on the RECURRENCE residual (as PETSc's bcgs does); what is reported is the true one,
@@ -1979,7 +2204,8 @@ int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double
         else { set_error("bad ksp_type"); return SNS_E_ARG; }
         SNS_TRY(rc);
         its_total += *its;
-        const bool retryable = *reason == SNS_KSP_DIVERGED_BREAKDOWN || *reason == SNS_KSP_DIVERGED_NANORINF;
+        const bool retryable = *reason == SNS_KSP_DIVERGED_BREAKDOWN || *reason == SNS_KSP_DIVERGED_NANORINF ||
+                               *reason == SNS_KSP_STALLED;
         if (!retryable || !can_retry || attempt == 1) break;
         h->last_first_reason = *reason;
         ++h->ctr_retries;
@@ -2062,10 +2288,18 @@ void sns_default_options(sns_options* o) {
     o->halo_overlap = 1;
     o->amg_fused_post = 1;
     o->amg_nu_scale_with_size = 1;
+    o->amg_dense_rows = 512;
+    o->amg_block_smooth = 1;
+    o->amg_bnu_l1 = 3;
+    o->amg_bnu_l2 = 3;
+    o->amg_bnu_deep = 1;
+    o->amg_block_max_rows = 65536;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
 const char* sns_version(void) { return "sns 0.1 (gfx950)"; }
+int sns_abi_version(void) { return SNS_ABI_VERSION; }
+int64_t sns_options_size(void) { return (int64_t)sizeof(sns_options); }
 
 // dim 3: points [n*3], cells [E*4];  dim 2: points [n*2], cells [E*3]
 static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_tets, const double* points_in,
@@ -2237,8 +2471,8 @@ int sns_destroy(sns_handle h) {
     fr(h->nt_ptr); fr(h->nt_idx); fr(h->c_ptr); fr(h->c_idx); fr(h->od_order); fr(h->gext); fr(h->Ke); fr(h->Fe);
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
-        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
-        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16);
+        fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.dense_gj); fr(L.dense_work); fr(L.dense_x32); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16); fr(L.blk_rows); fr(L.binv32);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);
@@ -2276,7 +2510,7 @@ int sns_set_stream(sns_handle h, void* s) {
 int sns_set_options(sns_handle h, const sns_options* o) {
     if (!h || !o) return SNS_E_ARG;
     const bool pc_changed = (o->pc_type != h->opt.pc_type) || (o->amg_f32_matrix != h->opt.amg_f32_matrix) ||
-                            (o->amg_fused_post != h->opt.amg_fused_post);
+                            (o->amg_fused_post != h->opt.amg_fused_post) || (o->amg_block_smooth != h->opt.amg_block_smooth);
     const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
     const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows) ||
                                         (o->amg_post_exchange != h->opt.amg_post_exchange);
@@ -2297,7 +2531,7 @@ int sns_set_options(sns_handle h, const sns_options* o) {
         }
     }
     if (pc_changed || damping_changed) h->pc_ready = false;
-    if (damping_changed)
+    if (damping_changed || pc_changed)
         for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }   // re-estimate and re-verify
     return SNS_OK;
 }
@@ -2388,6 +2622,9 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
         for (size_t i = (size_t)4 * n_owned; i < fm.size(); ++i) fm[i] = 0;
         HIP_TRY(hipMemcpy(h->levels[0].free_mask, fm.data(), fm.size(), hipMemcpyHostToDevice));
     }
+    // first collective of the communicator: both ends of every link agree on its counts (the coarse levels' plans are
+    // checked the same way when the hierarchy derives them)
+    SNS_TRY(check_plan_symmetry(h, c.plans[0], 0));
     return SNS_OK;
 }
 
@@ -2642,6 +2879,30 @@ int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t 
         if (sweeps) sweeps[l] = l + 1 < (int)h->levels.size() ? level_nu(h, l) : 0;      // the coarsest level is a dense inverse
         if (omega) omega[l] = L.omega;
     }
+    return SNS_OK;
+}
+int sns_dense_inverse(int device, int32_t N, const double* A, double* Ainv) {
+    if (N <= 0 || !A || !Ainv) return SNS_E_ARG;
+    HIP_TRY(hipSetDevice(device));
+    const int Np = (N + 63) / 64 * 64;
+    double *W = nullptr, *work = nullptr;
+    int* sing = nullptr;
+    SNS_TRY(dev_alloc(&W, (size_t)Np * Np));
+    SNS_TRY(dev_alloc(&work, dense_gj_work_doubles(Np)));
+    SNS_TRY(dev_alloc(&sing, 1));
+    HIP_TRY(hipMemset(sing, 0, sizeof(int)));
+    HIP_TRY(hipMemset(W, 0, (size_t)Np * Np * sizeof(double)));
+    HIP_TRY(hipMemcpy2D(W, (size_t)Np * sizeof(double), A, (size_t)N * sizeof(double), (size_t)N * sizeof(double), N,
+                        hipMemcpyDeviceToDevice));
+    if (Np > N) hipLaunchKernelGGL(k_dense_pad_diag, dim3((Np - N + 255) / 256), dim3(256), 0, nullptr, N, Np, W);
+    dense_gj_inverse(nullptr, Np, W, work, sing);
+    HIP_TRY(hipMemcpy2D(Ainv, (size_t)N * sizeof(double), W, (size_t)Np * sizeof(double), (size_t)N * sizeof(double), N,
+                        hipMemcpyDeviceToDevice));
+    int hs = 0;
+    HIP_TRY(hipMemcpy(&hs, sing, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(W); (void)hipFree(work); (void)hipFree(sing);
+    HIP_TRY(hipGetLastError());
+    if (hs) { set_error("sns_dense_inverse: zero or non-finite pivot"); return SNS_E_STATE; }
     return SNS_OK;
 }
 int sns_get_timings(sns_handle h, sns_timings* t) {

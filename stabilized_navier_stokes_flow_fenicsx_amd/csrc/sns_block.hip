@@ -1,0 +1,317 @@
+// Aggregate-block Jacobi smoother for the coarse levels of the AMG hierarchy (round 4).
+//
+// The damped point-block (4 x 4 per node) Jacobi sweep is what limits the plain-aggregation V-cycle on this non-symmetric,
+// saddle-point-like operator: level 1 needs 1 + 6 sweeps, level 2 6 + 6, and below the fine level every
+// sweep is a dependent, latency-bound launch.  Here the block of the Jacobi splitting is a whole AGGREGATE -- the <= 8 nodes
+// (32 dofs) that become one node of the next level:
+//     x <- x + w B^-1 (b - A x),      B = blockdiag over the aggregates of A,
+// one sweep = one launch like before, but it is worth about two point sweeps (oracle/experiments/r4_block_smoother.py: level 1
+// 1 + 3 and level 2 2 + 2 sweeps reach the iteration count of 1 + 6 and 6 + 6).
+//
+// Layout: the 32 lanes of a half-wave take one aggregate -- 4 lanes per member row exactly as in k_spmv_lp (lane 4 q + c:
+// member q, dof c), the member rows through the padded list blk_rows[8 G + q] (-1: the aggregate has fewer members).  Each
+// quad computes its row's residual with the level's low-precision matrix copy (same stepped loop as k_spmv_lp), the 32
+// residual entries meet in LDS and lane j multiplies them with row j of the aggregate's inverse B_G^-1 (fp32, 4 KiB per
+// aggregate, stored [k/4][j] as float4 so that a half-wave reads 512 contiguous bytes per instruction; requested before the
+// row loop).  Vectors and arithmetic stay fp64: the cycle remains a fixed linear operator.
+// B_G^-1 is rebuilt at every numeric setup by k_binv (gather of the aggregate's diagonal block from the fp64 level operator,
+// 32 x 32 Gauss-Jordan in LDS without pivoting -- principal submatrices of an operator with positive definite symmetric part).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sns_kernels.h"
+
+namespace sns {
+
+namespace {
+
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_b(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ double qb(double v) { return quad_perm_b<J * 0x55>(v); }
+template <int J>
+__device__ __forceinline__ double2 qb2(const double2 v) { return make_double2(qb<J>(v.x), qb<J>(v.y)); }
+
+__device__ __forceinline__ double lp_dot_b(const float4 a, const double2 xa, const double2 xb) {
+    return (double)a.x * xa.x + (double)a.y * xa.y + (double)a.z * xb.x + (double)a.w * xb.y;
+}
+__device__ __forceinline__ double lp_dot_b(const f16x4_t a, const double2 xa, const double2 xb) {
+    return (double)(float)a.x * xa.x + (double)(float)a.y * xa.y + (double)(float)a.z * xb.x + (double)(float)a.w * xb.y;
+}
+
+// sum_k A_rk x_k for dof row r (= lane & 3) of the block row [s, e) of a low-precision level matrix (FMT 1: fp32 blocks, FMT 2:
+// fp16 pair-interleaved blocks; the row scale of FMT 2 is applied by the caller).  The stepped loop of k_spmv_lp: one index load
+// per quad and step of 4 blocks (requested one step ahead), the x gather as whole blocks handed round by DPP.  s, e are quad-uniform.
+template <int FMT>
+__device__ __forceinline__ double lp_row_times_x(int32_t s, int32_t e, const int32_t* __restrict__ colind,
+                                                 const void* __restrict__ vals_v, const double* __restrict__ x, int r) {
+    double acc0 = 0.0, acc1 = 0.0;
+    const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);
+    const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);
+    int32_t k = s;
+    int32_t cnext = (k + 3 < e) ? colind[k + r] : 0;
+    for (; k + 3 < e; k += 4) {
+        const int32_t cme = cnext;
+        if (k + 7 < e) cnext = colind[k + 4 + r];
+        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];
+        if (FMT == 1) {
+            const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
+            acc0 += lp_dot_b(a0, qb2<0>(xa), qb2<0>(xb));
+            acc1 += lp_dot_b(a1, qb2<1>(xa), qb2<1>(xb));
+            acc0 += lp_dot_b(a2, qb2<2>(xa), qb2<2>(xb));
+            acc1 += lp_dot_b(a3, qb2<3>(xa), qb2<3>(xb));
+            v32 += 16;
+        } else {
+            const uint4 p0 = v16[0], p1 = v16[4];
+            const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0), h1 = *reinterpret_cast<const f16x8_t*>(&p1);
+            acc0 += lp_dot_b(h0.lo, qb2<0>(xa), qb2<0>(xb));
+            acc1 += lp_dot_b(h0.hi, qb2<1>(xa), qb2<1>(xb));
+            acc0 += lp_dot_b(h1.lo, qb2<2>(xa), qb2<2>(xb));
+            acc1 += lp_dot_b(h1.hi, qb2<3>(xa), qb2<3>(xb));
+            v16 += 8;
+        }
+    }
+    if (k < e) {                                                  // 1..3 blocks left; quad-uniform
+        const int32_t left = e - k;
+        const int32_t cme = colind[k + (r < left ? r : 0)];
+        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        const double2 xa = xp[0], xb = xp[1];
+        if (FMT == 1) {
+            acc0 += lp_dot_b(v32[0], qb2<0>(xa), qb2<0>(xb));
+            if (left > 1) acc1 += lp_dot_b(v32[4], qb2<1>(xa), qb2<1>(xb));
+            if (left > 2) acc0 += lp_dot_b(v32[8], qb2<2>(xa), qb2<2>(xb));
+        } else {
+            if (left > 1) {
+                const uint4 p0 = v16[0];
+                const f16x8_t h0 = *reinterpret_cast<const f16x8_t*>(&p0);
+                acc0 += lp_dot_b(h0.lo, qb2<0>(xa), qb2<0>(xb));
+                acc1 += lp_dot_b(h0.hi, qb2<1>(xa), qb2<1>(xb));
+            }
+            if (left & 1) {                                       // the odd last block: plain layout, 8 B per row
+                const uint2 q = reinterpret_cast<const uint2*>(vals_v)[(int64_t)(e - 1) * 4 + r];
+                const f16x4_t hq = *reinterpret_cast<const f16x4_t*>(&q);
+                if (left == 1) acc0 += lp_dot_b(hq, qb2<0>(xa), qb2<0>(xb));
+                else acc0 += lp_dot_b(hq, qb2<2>(xa), qb2<2>(xb));
+            }
+        }
+    }
+    return acc0 + acc1;
+}
+
+// (B_G^-1 res)[j] for lane j of the half-wave that holds aggregate G's residual (one entry per lane); sr = this half-wave's 32
+// doubles of LDS.  Every thread of the workgroup must call it (barrier inside).
+__device__ __forceinline__ double block_apply(const float4 (&Bv)[8], double res, double* __restrict__ sr, int j) {
+    sr[j] = res;
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        const double2 r01 = *reinterpret_cast<const double2*>(sr + 4 * k4), r23 = *reinterpret_cast<const double2*>(sr + 4 * k4 + 2);
+        a0 += (double)Bv[k4].x * r01.x + (double)Bv[k4].z * r23.x;
+        a1 += (double)Bv[k4].y * r01.y + (double)Bv[k4].w * r23.y;
+    }
+    return a0 + a1;
+}
+
+}  // namespace
+
+// one sweep  y = x + w B^-1 (b - A x)  over the aggregates' member rows; n_slots = 8 * number of aggregates
+template <int FMT>
+__global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* __restrict__ blk_rows,
+                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                const void* __restrict__ vals_v, const float* __restrict__ scale,
+                                                const float4* __restrict__ binv, const double* __restrict__ x,
+                                                double* __restrict__ y, const double* __restrict__ bvec, double omega) {
+    __shared__ double sres[8 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
+    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t row = in ? blk_rows[slot] : -1;
+    const bool live = row >= 0;
+    float4 Bv[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4)
+        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
+    if (live) {
+        if (FMT == 2) sc = (double)scale[4 * (int64_t)row + r];
+        pre_b = bvec[4 * (int64_t)row + r];
+        pre_x = x[4 * (int64_t)row + r];
+    }
+    const double acc = sc * lp_row_times_x<FMT>(s, e, colind, vals_v, x, r);
+    const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
+    if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
+}
+template __global__ void k_bsweep<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
+                                     const float4*, const double*, double*, const double*, double);
+template __global__ void k_bsweep<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
+                                     const float4*, const double*, double*, const double*, double);
+
+// coarse-grid correction + first post-smoothing sweep over M = A P with the aggregate blocks (k_post_lp's algebra):
+//     y = (x1 + P xc) + w B^-1 (r1 - M xc)
+template <int FMT>
+__global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* __restrict__ blk_rows,
+                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                               const void* __restrict__ vals_v, const float* __restrict__ scale,
+                                               const float4* __restrict__ binv, const double* __restrict__ xc,
+                                               const double* __restrict__ x_pre, const double* __restrict__ res1, double omega,
+                                               const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
+                                               double* __restrict__ y) {
+    __shared__ double sres[8 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
+    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t row = in ? blk_rows[slot] : -1;
+    const bool live = row >= 0;
+    float4 Bv[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4)
+        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
+    if (live) {
+        const int32_t I = agg[row];
+        if (FMT == 2) sc = (double)scale[4 * (int64_t)row + r];
+        pre_b = res1[4 * (int64_t)row + r];
+        pre_x = x_pre[4 * (int64_t)row + r];
+        if (I >= 0 && (!free_mask || free_mask[4 * (int64_t)row + r])) pre_x += xc[4 * (int64_t)I + r];   // (x1 + P xc)_row
+    }
+    const double acc = sc * lp_row_times_x<FMT>(s, e, colind, vals_v, xc, r);
+    const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
+    if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
+}
+template __global__ void k_bpost<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
+                                    const float4*, const double*, const double*, const double*, double, const int32_t*,
+                                    const uint8_t*, double*);
+template __global__ void k_bpost<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
+                                    const float4*, const double*, const double*, const double*, double, const int32_t*,
+                                    const uint8_t*, double*);
+
+// z = w B^-1 b: the first sweep of a cycle (zero initial guess); with w = 1 the B^-1 of the spectral estimate
+__global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* __restrict__ blk_rows,
+                                                const float4* __restrict__ binv, const double* __restrict__ bvec, double omega,
+                                                double* __restrict__ z) {
+    __shared__ double sres[8 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
+    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t row = in ? blk_rows[slot] : -1;
+    const bool live = row >= 0;
+    float4 Bv[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4)
+        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const double zz = block_apply(Bv, live ? bvec[4 * (int64_t)row + r] : 0.0, sres + 32 * (tid >> 5), j);
+    if (live) z[4 * (int64_t)row + r] = omega * zz;
+}
+
+// Restriction to a level that is smoothed with aggregate blocks, fused with that level's first sweep from the zero guess:
+//     bc[I] = sum_{i in I} free_i r[i]   (k_restrict's gather, same member order => same bits),     z = w_c B_c^-1 bc.
+// The coarse nodes are walked in the order of THEIR aggregates (blk_rows_c of the coarse level), so that the 32 lanes of a
+// half-wave hold one coarse aggregate's right-hand side when it is complete -- one dependent launch less per level and cycle.
+__global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int32_t* __restrict__ blk_rows_c,
+                                                      const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
+                                                      const uint8_t* __restrict__ free_mask, const double* __restrict__ r,
+                                                      double* __restrict__ bc, const float4* __restrict__ binv_c, double omega_c,
+                                                      double* __restrict__ z_c) {
+    __shared__ double sres[8 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
+    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t I = in ? blk_rows_c[slot] : -1;
+    const bool live = I >= 0;
+    float4 Bv[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4)
+        Bv[k4] = in ? binv_c[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    double s = 0.0;
+    if (live) {
+        const int32_t k0 = m_ptr[I], k1 = m_ptr[I + 1];
+        for (int32_t k = k0; k < k1; k += 8) {                     // all member ids of a batch first, then their residual entries
+            int32_t m[8];
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = (k + q < k1) ? m_idx[k + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t d = 4 * (int64_t)(m[q] < 0 ? 0 : m[q]) + c;
+                v[q] = (m[q] >= 0 && (!free_mask || free_mask[d])) ? r[d] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        bc[4 * (int64_t)I + c] = s;
+    }
+    const double zz = block_apply(Bv, live ? s : 0.0, sres + 32 * (tid >> 5), j);
+    if (live) z_c[4 * (int64_t)I + c] = omega_c * zz;
+}
+
+// B_G^-1 of every aggregate from the level's fp64 operator: 8 aggregates per workgroup, 32 lanes each (lane j = column j of the
+// 32 x 32 block in LDS).  Member slots an aggregate does not fill keep identity rows / columns.
+__global__ __launch_bounds__(256) void k_binv(int32_t nagg, const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
+                                              const int32_t* __restrict__ agg, const int32_t* __restrict__ rowptr,
+                                              const int32_t* __restrict__ colind, const double* __restrict__ vals,
+                                              float4* __restrict__ binv, int* __restrict__ singular) {
+    __shared__ double lds[8 * 32 * 33];
+    const int tid = threadIdx.x, ha = tid >> 5, j = tid & 31;
+    const int32_t G = (int32_t)blockIdx.x * 8 + ha;
+    double* __restrict__ M = lds + ha * 32 * 33;
+    for (int i = 0; i < 32; ++i) M[i * 33 + j] = (i == j) ? 1.0 : 0.0;
+    __syncthreads();
+    if (G < nagg) {
+        const int32_t k0 = m_ptr[G];
+        const int cnt = min(8, m_ptr[G + 1] - k0);
+        const int q = j >> 2, sub = j & 3;
+        if (q < cnt) {
+            const int32_t row = m_idx[k0 + q];
+            for (int32_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 4) {
+                const int32_t jn = colind[k];
+                if (agg[jn] != G) continue;
+                int lj = -1;
+                for (int t = 0; t < cnt; ++t)
+                    if (m_idx[k0 + t] == jn) lj = t;
+                if (lj < 0) continue;
+                const double* __restrict__ blkv = vals + (int64_t)k * 16;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) M[(4 * q + rr) * 33 + 4 * lj + cc] = blkv[4 * rr + cc];
+            }
+        }
+    }
+    __syncthreads();
+    // in-place Gauss-Jordan, lane j owns column j; the lanes of a wave run in lockstep, so every row's old M[i][p] is read by all
+    // of them before lane p overwrites it
+    for (int p = 0; p < 32; ++p) {
+        const double piv = M[p * 33 + p];
+        if (j == 0 && !(fabs(piv) > 1e-300 && fabs(piv) < 1e300)) *singular = 1;
+        const double d = 1.0 / piv;
+        const double prc = (j == p) ? d : M[p * 33 + j] * d;
+        for (int i = 0; i < 32; ++i) {
+            if (i == p) continue;
+            const double f = M[i * 33 + p];
+            const double cur = M[i * 33 + j];
+            M[i * 33 + j] = (j == p) ? -f * d : cur - f * prc;
+        }
+        M[p * 33 + j] = prc;
+        __syncthreads();
+    }
+    if (G < nagg) {
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4)
+            binv[((int64_t)G * 8 + k4) * 32 + j] = make_float4((float)M[j * 33 + 4 * k4], (float)M[j * 33 + 4 * k4 + 1],
+                                                               (float)M[j * 33 + 4 * k4 + 2], (float)M[j * 33 + 4 * k4 + 3]);
+    }
+}
+
+}  // namespace sns

@@ -58,6 +58,7 @@ void build_coarse_from_agg(const HostPattern& F, int32_t n_owned_fine, const std
 struct Level {
     int32_t n = 0;                       // local block rows (owned + ghost on level 0)
     int32_t n_owned = 0;                 // rows that are solved for (== n when serial)
+    int64_t n_global = 0;                // rows of this level over all ranks (a replicated level: its own rows)
     int64_t nnzb = 0;
     int32_t *rowptr = nullptr, *colind = nullptr, *diag = nullptr;
     double* vals = nullptr;              // nnzb*16, block row-major
@@ -81,11 +82,22 @@ struct Level {
     float* ap_vals32 = nullptr;
     void* ap_vals16 = nullptr;
     float* ap_scale16 = nullptr;
+    // aggregate-block Jacobi smoother (amg_block_smooth, csrc/sns_block.hip): member rows of every aggregate padded to 8 slots
+    // (-1: none), built with the hierarchy; the aggregates' inverse diagonal blocks (fp32, 1024 floats each) per numeric setup
+    int32_t* blk_rows = nullptr;
+    int32_t n_blk = 0;                   // aggregates covered (= nc)
+    float* binv32 = nullptr;
     // work vectors (4*n doubles)
     double *x = nullptr, *b = nullptr, *r = nullptr;
     double* xg = nullptr;                // distributed runs: copy of the iterate whose ghost tail is exchanged
     // coarsest level: dense inverse (4n x 4n), row-major
     double* dense_inv = nullptr;
+    // ... or, for a coarsest level of up to amg_dense_rows rows, the blocked Gauss-Jordan inverse (csrc/sns_dense.hip): the
+    // Np x Np fp64 matrix the elimination works in (Np = 4n rounded up to a multiple of 64), its workspace, and the finished
+    // inverse as fp32 (leading dimension Np) for the cycle's matvec
+    int dense_np = 0;
+    double *dense_gj = nullptr, *dense_work = nullptr;
+    float* dense_x32 = nullptr;
     // block-Jacobi damping actually used on this level (<= amg_omega, limited by 4/(3 |lambda|max(Dinv A)))
     double omega = 0.8;
     double lambda_max = 0.0;

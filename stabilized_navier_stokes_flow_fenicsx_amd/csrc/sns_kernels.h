@@ -73,6 +73,8 @@ __global__ void k_bjacobi(int32_t n, const double* dinv, const double* r, double
 __global__ void k_bjacobi32(int32_t n, const float* dinv32, const double* r, double omega, double* z);
 __global__ void k_reduce_final(int nblocks, int nred, const double* partial, double* out);
 __global__ void k_reduce_chunks(int nblocks, int nred, const double* partial, double* out);
+template <int WHICH>
+__global__ void k_reduce_final_bicg(int nblocks, const double* partial, double* red_out, double* sc);
 __global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);
 __global__ void k_axpby(int64_t n, double a, const double* x, double b, double* y);
 __global__ void k_axpbypcz(int64_t n, double a, const double* x, double b, const double* y, double c, double* z);
@@ -107,6 +109,26 @@ __global__ void k_dense_matvec(int N, const double* D, const double* x, double* 
 __global__ void k_bsr_to_dense_map(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                                    const int32_t* colmap, int N, double* D);
 __global__ void k_pad_identity(int r0, int r1, int g0, int N, double* D);
+// csrc/sns_dense.hip: blocked Gauss-Jordan inverse of the dense coarsest level on the fp64 matrix cores + its fp32 matvec
+__global__ void k_bsr_to_dense_ld(int64_t nnzb, const int32_t* slot_row, const int32_t* colind, const double* vals, int Np, double* D);
+__global__ void k_dense_pad_diag(int N, int Np, double* D);
+__global__ void k_dense_to_f32(int64_t n, const double* A, float* X);
+__global__ void k_dense_matvec32(int N, int Np, const float* X, const double* b, double* y);
+void dense_gj_inverse(hipStream_t s, int Np, double* A, double* work, int* singular);
+inline size_t dense_gj_work_doubles(int Np) { return (size_t)2 * 64 * Np + 4 * 4096; }
+// csrc/sns_block.hip: aggregate-block Jacobi smoother of the coarse levels
+template <int FMT>
+__global__ void k_bsweep(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
+                         const float* scale, const float4* binv, const double* x, double* y, const double* bvec, double omega);
+template <int FMT>
+__global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
+                        const float* scale, const float4* binv, const double* xc, const double* x_pre, const double* res1,
+                        double omega, const int32_t* agg, const uint8_t* free_mask, double* y);
+__global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const float4* binv, const double* bvec, double omega, double* z);
+__global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
+                               const uint8_t* free_mask, const double* r, double* bc, const float4* binv_c, double omega_c, double* z_c);
+__global__ void k_binv(int32_t nagg, const int32_t* m_ptr, const int32_t* m_idx, const int32_t* agg, const int32_t* rowptr,
+                       const int32_t* colind, const double* vals, float4* binv, int* singular);
 __global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
 __global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
 __global__ void k_fill_pattern(int64_t n, double* x);

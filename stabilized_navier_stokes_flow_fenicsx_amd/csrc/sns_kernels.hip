@@ -2144,6 +2144,42 @@ __global__ __launch_bounds__(256) void k_reduce_final(int nblocks, int nred, con
     if (threadIdx.x == 0) out[k] = red[0];
 }
 
+// BiCGStab on one GPU (no all-reduce between the sum and its use): the final stage of the reduction and the scalar update that
+// consumes it in ONE single-workgroup launch instead of k_reduce_final + k_bicg_alpha / k_bicg_omega (a dependent launch less
+// per half iteration).  The sums are formed exactly as k_reduce_final forms them (same order, same bits).
+__device__ void bicg_alpha_update(double* __restrict__ sc, const double* __restrict__ red);
+__device__ void bicg_omega_update(double* __restrict__ sc, const double* __restrict__ red);
+template <int WHICH>    // 1: nred = 1, alpha;  2: nred = 5, omega / rho / beta / ||r||^2 / flags
+__global__ __launch_bounds__(256) void k_reduce_final_bicg(int nblocks, const double* __restrict__ partial,
+                                                           double* __restrict__ red_out, double* __restrict__ sc) {
+    constexpr int NRED = WHICH == 1 ? 1 : 5;
+    __shared__ double red[NRED][256];
+    __shared__ double tot[NRED];
+    double s[NRED];
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) s[k] += partial[(int64_t)b * NRED + k];
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {                 // the tree of k_reduce_final, all NRED columns per barrier
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) { tot[k] = red[k][0]; red_out[k] = red[k][0]; }
+        if (WHICH == 1) bicg_alpha_update(sc, tot);
+        else bicg_omega_update(sc, tot);
+    }
+}
+template __global__ void k_reduce_final_bicg<1>(int, const double*, double*, double*);
+template __global__ void k_reduce_final_bicg<2>(int, const double*, double*, double*);
+
 // first stage of a long reduction: block (c, k) sums partial[b][k] over the 2048 blocks b of chunk c (fixed order)
 __global__ __launch_bounds__(256) void k_reduce_chunks(int nblocks, int nred, const double* __restrict__ partial,
                                                        double* __restrict__ out) {
@@ -2222,11 +2258,12 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* __restr
         p[i] = r[i] + beta * (p[i] - omega * v[i]);
 }
 // alpha = rho / <rhat, v>
+__device__ void bicg_alpha_update(double* __restrict__ sc, const double* __restrict__ red) {
+    sc[6] = red[0];
+    sc[1] = sc[0] / red[0];
+}
 __global__ void k_bicg_alpha(double* __restrict__ sc, const double* __restrict__ red) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sc[6] = red[0];
-        sc[1] = sc[0] / red[0];
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) bicg_alpha_update(sc, red);
 }
 // s = r - alpha v
 __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restrict__ r, const double* __restrict__ sc,
@@ -2254,6 +2291,9 @@ __global__ __launch_bounds__(256) void k_bicg_dots5(int64_t n, const double* __r
 // omega, next rho, beta of the NEXT iteration, ||r||^2 and the flags; out[0..1] = (||r||^2, flags) for the host
 __global__ void k_bicg_omega(double* __restrict__ sc, const double* __restrict__ red) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bicg_omega_update(sc, red);
+}
+__device__ void bicg_omega_update(double* __restrict__ sc, const double* __restrict__ red) {
     const double ts = red[0], tt = red[1], hs = red[2], ht = red[3], ss = red[4];
     const double omega = (tt > 0.0) ? ts / tt : 0.0;
     const double rho_new = hs - omega * ht;

@@ -264,8 +264,38 @@ def test_bench_repeats_a_crashed_launch_once_without_the_two_stream_overlap():
     assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "SNS_NO_OVERLAP=1 after a first attempt that exited" in d["launch_fallback"]
+    # the fallback is not a silent success -- the line is marked degraded and the first attempt's exit code and
+    # stderr tail are on file
+    assert d["degraded"] is True
+    rec = d["launch_fallback"].split("record: ")[1].rstrip(")")
+    assert os.path.exists(rec) and "first attempt (overlapped halo) exited" in open(rec).read()
+    os.remove(rec)
     rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"])
-    assert rc == 0 and json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])["launch_fallback"] is None
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert rc == 0 and d["launch_fallback"] is None and d["degraded"] is False
+
+
+def test_bench_weak_leg_deadline_keeps_the_headline_line():
+    """a weak-scaling leg that hangs (here: on both ranks, for good) must not cost the headline.  After
+    --weak-timeout seconds rank 0 prints THE line with weak_scaling = {error: timeout ...}, every rank leaves with exit code 0
+    (no re-exec, no child), and the launcher reports success with exactly one line."""
+    import json
+    import time
+    t0 = time.time()
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6", "--weak-timeout", "3"],
+                              {"SNS_DRYRUN_WEAK_STALL": "1", "SNS_WATCHDOG_S": "600"}, timeout=300)
+    assert rc == 0, err[-2000:]
+    assert time.time() - t0 < 200
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "timeout" in d["weak_scaling"]["error"]
+    assert "weak-scaling leg exceeded" in err
+    # in-process: a leg that finishes in time returns normally and leaves the line to the caller
+    import bench
+    o = {"weak_scaling": None}
+    bench.run_weak_leg_guarded(o, 0, 30.0, lambda: o.__setitem__("weak_scaling", {"value": 1.0}))
+    assert o["weak_scaling"] == {"value": 1.0}
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

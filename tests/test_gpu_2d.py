@@ -163,13 +163,22 @@ def test_dfg2d_constants_on_the_3d_tet_path():
     """The same pin for the 3-D kernels, i.e. for north_star's own path: DFG 2D-1 on a one-cell slab of tets
     (mesh2d.dfg2d_slab_problem: u_z = 0 on both z planes, so the continuous 3-D problem is the 2-D one), the 3-D G-metric
     SUPG/PSPG/LSIC forms of NavierStokesChannelFlow.py:220-251 AS WRITTEN (corrected_convection = 0) and with the
-    consistent (u.grad)u in the stabilisation terms (= 1), 3-D traction functional per unit depth.  Both must converge to
-    C_d = 5.57953523384 at first order (the functional takes the P1 gradient of the tet behind each facet) and they do so
-    from opposite sides -- measured, levels 2 / 4 / 8 / 12 / 16:  literal +0.705 / +0.324 / +0.205 / +0.108 / +0.054 %,
-    consistent -0.425 / -0.228 / -0.104 / -0.059 / -0.044 %.  C_l (0.2 % of the drag force) ends within 6 %."""
+    consistent (u.grad)u in the stabilisation terms (= 1), 3-D traction functional per unit depth.  Round 4 runs the whole
+    series the docstring of round 3 only quoted: levels 2 / 4 / 8 / 12 / 16 (78 k ... 4.08 M tets).  Measured C_d errors:
+    literal +0.705 / +0.324 / +0.205 / +0.108 / +0.054 %, consistent -0.425 / -0.228 / -0.104 / -0.059 / -0.044 %.
+    What is asserted (tolerances = what the series delivers):
+      * both forms converge towards C_d = 5.57953523384 (DFG_2D_Validation.py:202) monotonically from level 4 on and bracket it
+        on EVERY level, so at level 16 the constant is pinned to the bracket's width, 0.10 %, whatever the reading of
+        dot(u, grad(.)) (:241, :247); each form alone is within 0.07 % there;
+      * the consistent form's series is regular enough for the observed-order Richardson value of the 2-D test (levels 4 / 8 / 16,
+        the reference value does not enter): q = 0.48, C_d* = 5.5802, asserted within 1e-3 absolute (1.8e-4 relative);
+        the literal form's series is NOT (its level-8 point sits high: q > 1), so it gets the plain bound above;
+      * C_l (0.2 % of the drag force) within 4 % at level 16 for both (observed +3.3 % / +2.5 %).
+    The levels are independent graded Delaunay meshes, not nested refinements, which is what limits the extrapolation."""
     from stabilized_navier_stokes_flow_fenicsx_amd import functionals as Fn
+    levels = (2, 4, 8, 12, 16)
     out = {0: [], 1: []}
-    for n in (2, 4, 8):
+    for n in levels:
         m3, (mask, g), thick = M2.dfg2d_slab_problem(n)
         for corrected in (0, 1):
             # residual entries scale with h^2 * thickness: the default snes_atol 1e-8 would stop after two digits
@@ -193,20 +202,26 @@ def test_dfg2d_constants_on_the_3d_tet_path():
             P.close()
     for corrected in (0, 1):
         ed = [abs(cd - M2.DFG2D_CD_REF) for cd, _ in out[corrected]]
-        assert ed[1] < 0.6 * ed[0] and ed[2] < 0.7 * ed[1]
-        assert ed[2] < 0.0025 * M2.DFG2D_CD_REF
-        assert abs(out[corrected][2][1] - M2.DFG2D_CL_REF) < 0.06 * M2.DFG2D_CL_REF
-        # first-order extrapolation from levels 4 and 8 (the functional is first order in h; the slab series is too
-        # short and too irregular for an observed-order fit): 2 c8 - c4 within 0.1 % of the reference constant
-        # (observed: literal +0.087 %, consistent +0.020 %)
-        cd_star = 2.0 * out[corrected][2][0] - out[corrected][1][0]
-        print(f"  3-D path, {'consistent' if corrected else 'literal'}: first-order extrapolation C_d* {cd_star:.6f} "
-              f"({100 * (cd_star / M2.DFG2D_CD_REF - 1):+.3f} %)")
-        assert abs(cd_star - M2.DFG2D_CD_REF) < 1e-3 * M2.DFG2D_CD_REF
+        assert ed[1] < 0.6 * ed[0]
+        assert ed[4] < ed[3] < ed[2] < ed[1]                    # monotone from level 4 on
+        assert ed[2] < 0.0025 * M2.DFG2D_CD_REF                 # level 8 (round 3's bound)
+        assert ed[4] < 0.0007 * M2.DFG2D_CD_REF                 # level 16: observed 0.054 % / 0.044 %
+        assert abs(out[corrected][4][1] - M2.DFG2D_CL_REF) < 0.04 * M2.DFG2D_CL_REF
+    # observed-order Richardson for the consistent form (levels 4 / 8 / 16: h halves twice)
+    c4, c8, c16 = out[1][1][0], out[1][2][0], out[1][4][0]
+    q = (c16 - c8) / (c8 - c4)
+    cd_star = c16 + (c16 - c8) * q / (1.0 - q)
+    print(f"  3-D path, consistent form: Richardson (levels 4/8/16) q {q:.4f} (observed order {-np.log2(q):.2f}), C_d* {cd_star:.6f} "
+          f"({cd_star - M2.DFG2D_CD_REF:+.2e} from the reference constant)")
+    assert 0.35 < q < 0.6
+    assert abs(cd_star - M2.DFG2D_CD_REF) < 1e-3
     # both readings of dot(u, grad(.)) (:241, :247) converge to the same constant: the reference-held numbers pin the
     # Galerkin terms, BC semantics, assembly, solver and functional, and cannot tell the two readings apart
     for (cd0, _), (cd1, _) in zip(out[0], out[1]):
         assert cd1 < M2.DFG2D_CD_REF < cd0                      # the two forms bracket the reference value on every level
+    width = out[0][4][0] - out[1][4][0]
+    print(f"  bracket at level 16: [{out[1][4][0]:.6f}, {out[0][4][0]:.6f}], width {100 * width / M2.DFG2D_CD_REF:.3f} % of C_d")
+    assert width < 0.0012 * M2.DFG2D_CD_REF
 
 
 def test_lid_driven_stokes_script_matches_oracle(tmp_path, monkeypatch):
