@@ -171,10 +171,18 @@ typedef struct {
                                a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*) */
     int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (3) */
     int    amg_bnu_deep;    /* ... and on levels >= 3 (1).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
-    int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank (65536): there a sweep is a
+    int    amg_ritz_limit;  /* 1 (default): on every level that runs 3 or more sweeps per cycle the damping is also capped by the
+                               STABILITY limit of the dominant Ritz values of S A (S = the smoother's block inverse) from 8 Arnoldi
+                               steps, w <= min 2 Re(theta) / |theta|^2: the power iteration of rounds 1-3 sees |lambda|max only,
+                               and on a convection-dominated coarse level the dominant eigenvalues are complex -- a damping above
+                               the limit is amplified by every one of the level's sweeps (jittered 120 x 30 x 30 duct, Re 200:
+                               level 1 at w = 0.68 against a limit of 0.45 stalls BiCGStab; oracle/experiments/r4_damping.py).
+                               0: the |lambda|max rule alone */
+    int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank (8192): there a sweep is a
                                latency-bound launch whatever it reads, and halving the sweeps halves the time; on a larger level
-                               the sweep is bandwidth-bound and the 4 KiB of inverse per aggregate cost half a pass again (10 M-tet
-                               duct, level 1 = 218 k rows: 1 + 3 block sweeps = +9 % iterations for no gain per iteration) */
+                               the sweep is bound by bytes and the 4 KiB of inverse per aggregate make it 1.7x a nodal-block sweep
+                               (27 k rows: 10 against 5.5 us; 218 k rows: +50 % bytes), so half the sweeps buy nothing and cost
+                               iterations (10 M-tet duct: +4 ... 9 %).  0 = no limit */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
@@ -318,6 +326,14 @@ int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t 
  * Gauss-Jordan elimination of csrc/sns_dense.hip (64 x 64 blocks, v_mfma_f64_16x16x4_f64 rank-64 updates, NO pivoting: meant for
  * matrices whose symmetric part is positive definite, like the level operators).  SNS_E_STATE on a zero / non-finite pivot. */
 int sns_dense_inverse(int device, int32_t N, const double* A_dev, double* Ainv_dev);
+/* the V-cycle as run: per level the smoother / solver kind and the sweeps before and after the coarse-grid correction (the
+ * first pre-sweep starts from the zero guess).  Tests restate the cycle from this (oracle/amg_cycle.py).                    */
+#define SNS_LEVEL_NODAL_BLOCKS      0   /* damped Jacobi with the 4 x 4 nodal blocks                                         */
+#define SNS_LEVEL_AGGREGATE_BLOCKS  1   /* damped Jacobi with the aggregates' dense blocks (amg_block_smooth)                */
+#define SNS_LEVEL_DIRECT            2   /* coarsest level: dense inverse by the one-workgroup Gauss-Jordan with pivoting     */
+#define SNS_LEVEL_DIRECT_BLOCKED    3   /* coarsest level: dense inverse by the blocked Gauss-Jordan of csrc/sns_dense.hip   */
+#define SNS_LEVEL_SWEEPS_ONLY       4   /* coarsest level too large for a direct solve: 1 + 8 nodal-block sweeps              */
+int sns_get_cycle(sns_handle h, int32_t* nlevels, int32_t kind[16], int32_t nu_pre[16], int32_t nu_post[16]);
 int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot,
@@ -365,6 +381,10 @@ int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* co
  * (MatMult's VecScatter overlap in the reference's PETSc).  rows_out [n_owned], *n_out entries are valid.        */
 int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind,
                            int32_t* rows_out, int32_t* n_out);
+
+/* eigenvalues of a small real upper-Hessenberg matrix (row-major n x n, n <= 32; entries below the first subdiagonal ignored):
+ * the Ritz values of the short Arnoldi process that caps the smoother damping (amg_ritz_limit).                          */
+int sns_host_hessenberg_eigs(int n, const double* H, double* re_out, double* im_out);
 
 #ifdef __cplusplus
 }

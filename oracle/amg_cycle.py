@@ -34,8 +34,23 @@ def nodal_block_inverse(A, n):
     return sp.bsr_matrix((np.linalg.inv(D), np.arange(n), np.arange(n + 1)), shape=(4 * n, 4 * n)).tocsr()
 
 
+def smoother_blocks(agg, nc):
+    """the product's smoother blocks: the aggregates, one of more than 8 nodes split into chunks of 8 in ascending node order"""
+    blk = np.empty_like(agg)
+    nb = 0
+    order = np.argsort(agg, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(agg, minlength=nc))])
+    for I in range(nc):
+        mem = order[ptr[I]:ptr[I + 1]]
+        for k in range(0, len(mem), 8):
+            blk[mem[k:k + 8]] = nb
+            nb += 1
+    return blk, nb
+
+
 def aggregate_block_inverse(A, agg, nc):
-    """blockdiag over the node sets agg == I of A, inverted, in the original numbering"""
+    """blockdiag over the smoother blocks (aggregates, see smoother_blocks) of A, inverted, in the original numbering"""
+    agg, nc = smoother_blocks(agg, nc)
     order = np.argsort(agg, kind="stable")
     dofs = (4 * order[:, None] + np.arange(4)[None]).ravel()
     Ap = A[dofs][:, dofs].tocsr()

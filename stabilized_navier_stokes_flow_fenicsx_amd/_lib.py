@@ -45,6 +45,7 @@ class SnsOptions(C.Structure):
         ("amg_bnu_l1", C.c_int),
         ("amg_bnu_l2", C.c_int),
         ("amg_bnu_deep", C.c_int),
+        ("amg_ritz_limit", C.c_int),
         ("amg_block_max_rows", C.c_int),
     ]
 
@@ -104,6 +105,7 @@ _SIGNATURES = [
     ("sns_comm_info", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("sns_get_hierarchy", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("sns_dense_inverse", C.c_int, [C.c_int, C.c_int32, _P, _P]),
+    ("sns_get_cycle", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("sns_reset_timings", C.c_int, [_H]),
     ("sns_time_kernels", C.c_int, [_H, C.c_int]),
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -114,6 +116,7 @@ _SIGNATURES = [
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
     ("sns_host_boundary_rows", C.c_int, [C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
+    ("sns_host_hessenberg_eigs", C.c_int, [C.c_int, _P, _P, _P]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 

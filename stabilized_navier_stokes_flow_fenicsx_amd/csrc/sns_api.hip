@@ -104,6 +104,8 @@ struct sns_ctx {
     std::vector<double> graph_sig;                // (omega per level, nu, nu_coarse, f32) the graph was captured with
     bool graph_disabled = false;
     int matrix_form = -1;
+    int est_form = -1;                           // form of the matrix the levels' spectral estimates were last taken from
+    double est_re = 0.0;                         // ... and its Reynolds number
     // reductions
     double* partial = nullptr;                   // [max(65536*8, n/32)]
     double* partial2 = nullptr;                  // second stage of long reductions
@@ -131,6 +133,8 @@ struct sns_ctx {
     hipEvent_t ev_x = nullptr, ev_side = nullptr;
     bool no_overlap = false;
     bool team_overlap = false;                       // SNS_TEAM_OVERLAP: the team transport takes the two-stream path too (tests)
+    double* arn_V = nullptr;                          // Arnoldi basis of the damping estimate, 9 vectors of the largest level >= ... asked for
+    size_t arn_cap = 0;
     double damping_backoff = 1.0;                    // < 1 after a failed AMG-preconditioned solve: all level dampings scaled (krylov())
     int64_t ctr_retries = 0;                         // damping retries since sns_reset_timings
     int last_first_reason = 0;                       // reason of the FIRST attempt of the last solve (0 = no retry happened)
@@ -204,7 +208,7 @@ void time_collect(sns_ctx* h) {
 
 // finish a two-stage reduction locally: partial[nblocks][nred] -> dst_dev[0..nred)
 void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
-    if (nblocks > 8192 && nred <= 8) {
+    if (nblocks > 40000 && nred <= 8) {
         // the fused SpMV+dot leaves one partial per 32 rows (54 k at 10 M tets): a single workgroup needs ~40 us
         // for that, 2048-wide chunks on many CUs first ~5 us
         const int nchunks = (nblocks + 2047) / 2048;
@@ -236,7 +240,7 @@ int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
     }
     const double* src = h->partial;
     int nb = nblocks;
-    if (nblocks > 8192) {                        // (as reduce_local: 2048-wide chunks on many CUs first)
+    if (nblocks > 40000) {                       // (as reduce_local: 2048-wide chunks on many CUs first)
         const int nchunks = (nblocks + 2047) / 2048;
         if (nchunks <= 4096) {
             hipLaunchKernelGGL(k_reduce_chunks, dim3(nchunks, NRED), dim3(256), 0, h->stream, nblocks, NRED, h->partial, h->partial2);
@@ -545,14 +549,25 @@ int upload_block_rows(sns_ctx* h, int l, Level& L, const std::vector<int32_t>& m
                       int32_t nc_owned) {
     const int mode = h->opt.amg_block_smooth;
     if (mode <= 0 || (l == 0 && mode < 2) || nc_owned < 0) return SNS_OK;
-    std::vector<int32_t> rows((size_t)8 * std::max(1, nc_owned), -1);
+    // blocks = aggregates; an aggregate of more than 8 nodes (a leftover node joined a full neighbour) is split in member order
+    std::vector<int32_t> rows, of((size_t)std::max(1, L.n), -1);
+    rows.reserve((size_t)8 * std::max(1, nc_owned));
+    int32_t nb = 0;
     for (int32_t G = 0; G < nc_owned; ++G) {
-        const int32_t cnt = m_ptr[(size_t)G + 1] - m_ptr[(size_t)G];
-        if (cnt > 8) return SNS_OK;
-        for (int32_t q = 0; q < cnt; ++q) rows[(size_t)8 * G + q] = m_idx[(size_t)m_ptr[(size_t)G] + q];
+        const int32_t k0 = m_ptr[(size_t)G], k1 = m_ptr[(size_t)G + 1];
+        for (int32_t k = k0; k < k1; k += 8) {
+            for (int32_t q = 0; q < 8; ++q) {
+                const int32_t node = (k + q < k1) ? m_idx[(size_t)k + q] : -1;
+                rows.push_back(node);
+                if (node >= 0) of[(size_t)node] = nb;
+            }
+            ++nb;
+        }
     }
-    L.n_blk = nc_owned;
+    if (rows.empty()) rows.assign(8, -1);
+    L.n_blk = nb;
     SNS_TRY(dev_upload(&L.blk_rows, rows, h->stream));
+    SNS_TRY(dev_upload(&L.blk_of, of, h->stream));
     return SNS_OK;
 }
 // Is level l smoothed with the aggregate blocks?  (options only, no device state: every rank of a partitioned run must answer alike)
@@ -1222,6 +1237,89 @@ int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     return SNS_OK;
 }
 
+// Stability limit of the smoother damping on level l from the dominant Ritz values of S A (S = the level's smoother blocks,
+// nodal or aggregate): M = 8 Arnoldi steps from the deterministic start vector of the power iteration (classical Gram-Schmidt
+// with one re-orthogonalisation, the FGMRES kernels; one host read per step), eigenvalues of the 8 x 8 Hessenberg matrix on the
+// host (sns_host_hessenberg_eigs).  |1 - w theta| < 1 needs w < 2 Re(theta) / |theta|^2: *limit = the minimum over the Ritz
+// values with |theta| >= 0.5 |theta|max (those a few Arnoldi steps have converged to).  The power iteration above sees the
+// modulus only; on a convection-dominated coarse level the dominant eigenvalues are complex, and a level that runs 1 + 6
+// sweeps amplifies a damping above the limit seven times per cycle (oracle/experiments/r4_damping.py).
+inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post);
+int arnoldi_ritz(sns_ctx* h, int l, double* theta_max, double* limit) {
+    constexpr int M = 8;
+    Level& L = h->levels[l];
+    const int32_t rows = L.n_owned;
+    const int64_t nd = 4 * (int64_t)rows;
+    *theta_max = 0.0;
+    *limit = 1e30;
+    if (rows <= 0) return SNS_OK;
+    const int g = vec_grid(nd);
+    const bool glob = uses_ghosts_in_sweeps(h, l, L);
+    if (glob) return SNS_OK;                           // (sweeps that see exchanged ghost values: not estimated here)
+    if (h->arn_cap < (size_t)(M + 1) * nd) {
+        if (h->arn_V) (void)hipFree(h->arn_V);
+        h->arn_V = nullptr;
+        SNS_TRY(dev_alloc(&h->arn_V, (size_t)(M + 1) * nd));
+        h->arn_cap = (size_t)(M + 1) * nd;
+    }
+    double* V = h->arn_V;
+    double* y = L.r;
+    double* zero = nullptr;
+    double* xin = nullptr;                              // the SpMV input needs the level's full length (ghost tail = 0)
+    SNS_TRY(get_vec(h, 13, &zero));
+    SNS_TRY(get_vec(h, 12, &xin));
+    HIP_TRY(hipMemsetAsync(zero, 0, nd * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(xin, 0, 4 * (size_t)L.n * sizeof(double), h->stream));
+    double* sc = h->d_scal + 192;                      // [0, 8) pass-1 coefficients, [8, 16) pass 2, [16, 18) (w.w, w.w)
+    hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, V);
+    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, V, V, h->partial);
+    reduce_local(h, g, 2, sc + 16);
+    hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, sc + 17, V, V);
+    std::vector<double> H((size_t)M * M, 0.0);
+    const bool lp = lp_format(h, L) != 0;
+    int m_done = 0;
+    for (int j = 0; j < M; ++j) {
+        double* vj = V + (size_t)j * nd;
+        double* w = V + (size_t)(j + 1) * nd;
+        HIP_TRY(hipMemcpyAsync(xin, vj, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // y = -A~ v (the copy the sweeps read) resp. + A v; w = S A v
+        if (lp) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, xin, y, zero, 0.0);
+        else launch_spmv<SPMV_AX>(h, L, rows, xin, y, nullptr, 0.0, nullptr);
+        launch_first_sweep(h, l, L, rows, y, lp ? -1.0 : 1.0, w);
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(k_multi_dot8, dim3(g), dim3(256), 0, h->stream, nd, j + 1, V, nd, w, h->partial);
+            reduce_local(h, g, 8, sc + 8 * pass);
+            hipLaunchKernelGGL(k_multi_axpy8, dim3(g), dim3(256), 0, h->stream, nd, j + 1, V, nd, sc + 8 * pass, -1.0, w,
+                               (double*)nullptr);
+        }
+        hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, w, w, h->partial);
+        reduce_local(h, g, 2, sc + 16);
+        double v[18];
+        SNS_TRY(fetch(h, sc, 18, v));
+        for (int k = 0; k <= j; ++k) H[(size_t)k * M + j] = v[k] + v[8 + k];
+        m_done = j + 1;
+        const double wn = std::sqrt(std::max(0.0, v[16]));
+        if (!(wn > 1e-12) || j + 1 == M) break;        // invariant subspace (tiny levels) or done
+        H[(size_t)(j + 1) * M + j] = wn;
+        hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, sc + 17, w, w);
+    }
+    std::vector<double> Hm((size_t)m_done * m_done), re((size_t)m_done), im((size_t)m_done);
+    for (int i = 0; i < m_done; ++i)
+        for (int j = 0; j < m_done; ++j) Hm[(size_t)i * m_done + j] = H[(size_t)i * M + j];
+    if (sns_host_hessenberg_eigs(m_done, Hm.data(), re.data(), im.data()) != SNS_OK) return SNS_OK;
+    double tmax = 0.0;
+    for (int i = 0; i < m_done; ++i) tmax = std::max(tmax, std::hypot(re[i], im[i]));
+    double lim = 1e30;
+    for (int i = 0; i < m_done; ++i) {
+        const double a2 = re[i] * re[i] + im[i] * im[i];
+        if (std::sqrt(a2) < 0.5 * tmax || !(a2 > 0.0)) continue;
+        lim = std::min(lim, 2.0 * std::max(re[i], 0.0) / a2);
+    }
+    *theta_max = tmax;
+    *limit = lim;
+    return SNS_OK;
+}
+
 // Growth factor per sweep of the damped block-Jacobi iteration matrix G_w = I - w Dinv A on the
 // dominant mode of Dinv A (left in pong[l] by estimate_lambda_max).  |lambda|max alone does not bound
 // the stable damping of a NON-symmetric operator (|1 - w lambda| < 1 needs w < 2 Re(lambda)/|lambda|^2):
@@ -1266,6 +1364,7 @@ int pc_setup(sns_ctx* h) {
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     const int nl = (h->opt.pc_type == SNS_PC_AMG) ? (int)h->levels.size() : 1;
     bool any_block = false;
+    const bool new_operator = h->matrix_form != h->est_form || h->opt.reynolds != h->est_re;
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
         const int32_t rows = L.n_owned;
@@ -1287,8 +1386,8 @@ int pc_setup(sns_ctx* h) {
             // the aggregates' inverse diagonal blocks, from the fp64 operator (what the nodal D^-1 is to the point smoother)
             if (!L.binv32) SNS_TRY(dev_alloc(&L.binv32, (size_t)1024 * std::max(1, L.n_blk)));
             if (L.n_blk > 0)
-                hipLaunchKernelGGL(k_binv, dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.m_ptr, L.m_idx,
-                                   L.agg, L.rowptr, L.colind, L.vals, (float4*)L.binv32, h->d_sing);
+                hipLaunchKernelGGL(k_binv, dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.blk_rows, L.blk_of,
+                                   L.rowptr, L.colind, L.vals, (float4*)L.binv32, h->d_sing);
             any_block = true;
         }
         L.omega = h->opt.amg_omega * h->damping_backoff;
@@ -1342,11 +1441,29 @@ int pc_setup(sns_ctx* h) {
             // the spectrum moves little between the Jacobians of one Newton sequence: re-estimate every 4th setup
             double lam = L.lambda_max;
             // (collective when the level's sweeps use exchanged ghost values: every rank takes part, rows or not)
-            if ((rows > 0 || uses_ghosts_in_sweeps(h, l, L)) && (!(lam > 0.0) || (h->pc_setups & 3) == 0))
+            // ... but not from the Stokes operator to a Jacobian (or to another Reynolds number): round 3 took the first three
+            // Jacobians' damping from the Stokes solve's estimate, which is what let level 1 of the jittered 120 x 30 x 30 duct
+            // run at w = 0.72 where its own spectrum allows 0.48 (tests/test_gpu_parity.py::test_damping_backoff_...)
+            if ((rows > 0 || uses_ghosts_in_sweeps(h, l, L)) && (!(lam > 0.0) || (h->pc_setups & 3) == 0 || new_operator))
                 SNS_TRY(estimate_lambda_max(h, l, &lam));
-            const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0;
+            const bool fresh = !(L.lambda_max > 0.0) || (h->pc_setups & 3) == 0 || new_operator;
             L.lambda_max = lam;
             if (lam > 0.0) L.omega = std::min(h->opt.amg_omega, (4.0 / 3.0) / lam) * h->damping_backoff;
+            // levels that run 3 or more sweeps per cycle: the stability limit of the dominant (complex) Ritz values as well
+            if (h->opt.amg_ritz_limit && l + 1 < nl) {
+                int a = 1, b = 1;
+                level_sweeps(h, l, a, b);
+                if (a + b >= 3) {
+                    if (fresh && rows > 0) {
+                        double tmax = 0.0, lim = 1e30;
+                        SNS_TRY(arnoldi_ritz(h, l, &tmax, &lim));
+                        L.ritz_limit = lim;
+                        if (h->opt.monitor)
+                            std::printf("    AMG level %d: Ritz |theta|max %.4f, damping limit 2 Re/|theta|^2 = %.4f\n", l, tmax, lim);
+                    }
+                    if (L.ritz_limit > 0.0) L.omega = std::min(L.omega, L.ritz_limit * h->damping_backoff);
+                }
+            }
             if (fresh && lam > 0.0) {
                 // verify the damping on the dominant mode; back off until a sweep contracts it by >= 10 %
                 for (int trial = 0; trial < 6; ++trial) {
@@ -1416,6 +1533,8 @@ int pc_setup(sns_ctx* h) {
         }
     }
     ++h->pc_setups;
+    h->est_form = h->matrix_form;
+    h->est_re = h->opt.reynolds;
     const bool check_sing = nl > 1 && (h->levels[nl - 1].dense_gj != nullptr || any_block);
     int* h_sing = reinterpret_cast<int*>(h->h_scal + 768);
     if (check_sing) HIP_TRY(hipMemcpyAsync(h_sing, h->d_sing, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1451,9 +1570,7 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
         const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
         if (block_active(h, l)) {
             if (!partitioned) { nu_pre = 1; nu_post = std::max(1, h->opt.amg_bnu_l1); }
-            return;
-        }
-        if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
+        } else if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
             nu_pre = 1;
             nu_post = nu + 2;
         }
@@ -2293,7 +2410,8 @@ void sns_default_options(sns_options* o) {
     o->amg_bnu_l1 = 3;
     o->amg_bnu_l2 = 3;
     o->amg_bnu_deep = 1;
-    o->amg_block_max_rows = 65536;
+    o->amg_ritz_limit = 1;
+    o->amg_block_max_rows = 8192;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -2472,7 +2590,7 @@ int sns_destroy(sns_handle h) {
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.dense_gj); fr(L.dense_work); fr(L.dense_x32); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
-        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16); fr(L.blk_rows); fr(L.binv32);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16); fr(L.blk_rows); fr(L.blk_of); fr(L.binv32);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);
@@ -2480,6 +2598,7 @@ int sns_destroy(sns_handle h) {
     for (auto p : h->kv) fr(p);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
     fr(h->d_piv); fr(h->d_sing); fr(h->rep_valmap); fr(h->rep_rowmap); fr(h->rep_vsend); fr(h->rep_vrecv); fr(h->rep_bsend); fr(h->rep_brecv);
+    fr(h->arn_V);
     fr(h->partial); fr(h->partial2); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
     if (h->coarse_graph) (void)hipGraphExecDestroy(h->coarse_graph);
@@ -2518,7 +2637,7 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     if (h->damping_backoff != 1.0) {                 // a retry's stronger damping does not outlive an options call
         h->damping_backoff = 1.0;
         h->pc_ready = false;
-        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }
+        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; L.ritz_limit = 0.0; }
     }
     if (sweep_exchange_changed) {
         // rank-local sweeps rely on ghost tails that are never written (zero); sweeps with exchanges fill them
@@ -2532,7 +2651,7 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     }
     if (pc_changed || damping_changed) h->pc_ready = false;
     if (damping_changed || pc_changed)
-        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; }   // re-estimate and re-verify
+        for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; L.ritz_limit = 0.0; }   // re-estimate and re-verify
     return SNS_OK;
 }
 int sns_get_options(sns_handle h, sns_options* o) {
@@ -2903,6 +3022,25 @@ int sns_dense_inverse(int device, int32_t N, const double* A, double* Ainv) {
     (void)hipFree(W); (void)hipFree(work); (void)hipFree(sing);
     HIP_TRY(hipGetLastError());
     if (hs) { set_error("sns_dense_inverse: zero or non-finite pivot"); return SNS_E_STATE; }
+    return SNS_OK;
+}
+int sns_get_cycle(sns_handle h, int32_t* nlevels, int32_t kind[16], int32_t nu_pre[16], int32_t nu_post[16]) {
+    if (!h || !nlevels || !kind || !nu_pre || !nu_post) return SNS_E_ARG;
+    const int nl = (int)std::min<size_t>(16, h->levels.size());
+    *nlevels = nl;
+    for (int l = 0; l < nl; ++l) {
+        const Level& L = h->levels[l];
+        nu_pre[l] = nu_post[l] = 0;
+        if (l + 1 == (int)h->levels.size() && nl > 1) {
+            kind[l] = L.dense_gj ? SNS_LEVEL_DIRECT_BLOCKED : (L.dense_inv || h->cg_N > 0) ? SNS_LEVEL_DIRECT : SNS_LEVEL_SWEEPS_ONLY;
+            continue;
+        }
+        kind[l] = block_active(h, l) ? SNS_LEVEL_AGGREGATE_BLOCKS : SNS_LEVEL_NODAL_BLOCKS;
+        int a = 1, b = 1;
+        level_sweeps(h, l, a, b);
+        nu_pre[l] = a;
+        nu_post[l] = b;
+    }
     return SNS_OK;
 }
 int sns_get_timings(sns_handle h, sns_timings* t) {

@@ -256,30 +256,30 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
     if (live) z_c[4 * (int64_t)I + c] = omega_c * zz;
 }
 
-// B_G^-1 of every aggregate from the level's fp64 operator: 8 aggregates per workgroup, 32 lanes each (lane j = column j of the
-// 32 x 32 block in LDS).  Member slots an aggregate does not fill keep identity rows / columns.
-__global__ __launch_bounds__(256) void k_binv(int32_t nagg, const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
-                                              const int32_t* __restrict__ agg, const int32_t* __restrict__ rowptr,
-                                              const int32_t* __restrict__ colind, const double* __restrict__ vals,
-                                              float4* __restrict__ binv, int* __restrict__ singular) {
+// B_G^-1 of every smoother block from the level's fp64 operator: 8 blocks per workgroup, 32 lanes each (lane j = column j of the
+// 32 x 32 block in LDS).  Member slots a block does not fill keep identity rows / columns.  (Blocks = the aggregates; the rare
+// aggregate of more than 8 nodes -- a leftover node joins a full neighbour -- is split into chunks of 8 in member order: the
+// smoother's partition need not be the coarsening's.  blk_of[node] = the block of a node, -1 for ghost nodes.)
+__global__ __launch_bounds__(256) void k_binv(int32_t nblk, const int32_t* __restrict__ blk_rows, const int32_t* __restrict__ blk_of,
+                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                              const double* __restrict__ vals, float4* __restrict__ binv,
+                                              int* __restrict__ singular) {
     __shared__ double lds[8 * 32 * 33];
     const int tid = threadIdx.x, ha = tid >> 5, j = tid & 31;
     const int32_t G = (int32_t)blockIdx.x * 8 + ha;
     double* __restrict__ M = lds + ha * 32 * 33;
     for (int i = 0; i < 32; ++i) M[i * 33 + j] = (i == j) ? 1.0 : 0.0;
     __syncthreads();
-    if (G < nagg) {
-        const int32_t k0 = m_ptr[G];
-        const int cnt = min(8, m_ptr[G + 1] - k0);
+    if (G < nblk) {
         const int q = j >> 2, sub = j & 3;
-        if (q < cnt) {
-            const int32_t row = m_idx[k0 + q];
+        const int32_t row = blk_rows[8 * (int64_t)G + q];
+        if (row >= 0) {
             for (int32_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 4) {
                 const int32_t jn = colind[k];
-                if (agg[jn] != G) continue;
+                if (blk_of[jn] != G) continue;
                 int lj = -1;
-                for (int t = 0; t < cnt; ++t)
-                    if (m_idx[k0 + t] == jn) lj = t;
+                for (int t = 0; t < 8; ++t)
+                    if (blk_rows[8 * (int64_t)G + t] == jn) lj = t;
                 if (lj < 0) continue;
                 const double* __restrict__ blkv = vals + (int64_t)k * 16;
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_binv(int32_t nagg, const int32_t* __res
         M[p * 33 + j] = prc;
         __syncthreads();
     }
-    if (G < nagg) {
+    if (G < nblk) {
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4)
             binv[((int64_t)G * 8 + k4) * 32 + j] = make_float4((float)M[j * 33 + 4 * k4], (float)M[j * 33 + 4 * k4 + 1],

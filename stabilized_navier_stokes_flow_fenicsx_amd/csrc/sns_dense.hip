@@ -10,7 +10,7 @@
 //                CpT_i = A[i, p]^T     for every block row i != p          (copies: the update below works in place)
 //   k_gj_update  A[i, j] -= A[i, p] R_j;  A[i, p] = -A[i, p] P^-1;  A[p, j] = R_j;  A[p, p] = P^-1,
 //                and the workgroup of tile (p+1, p+1) inverts its freshly updated tile in LDS: the next step's P^-1.
-// No pivoting across blocks (and none inside: the diagonal tiles are inverted by plain Gauss-Jordan in LDS): the level
+// No pivoting across blocks (and none inside: the diagonal tiles are inverted by a block Gauss-Jordan of their own, see invert64): the level
 // operators are Galerkin projections of the stabilised form, whose symmetric part is positive definite (viscous + SUPG/LSIC
 // terms on the velocity block, the PSPG Laplacian on the pressure block; Dirichlet and empty coarse dofs are identity rows), so
 // every leading principal block is nonsingular and the element growth of the elimination is bounded by the ratio of the skew
@@ -66,52 +66,104 @@ __device__ __forceinline__ void tile_mfma(const double* __restrict__ At, const d
     }
 }
 
-// Inverse of a 64 x 64 tile by Gauss-Jordan without pivoting, the tile held in REGISTERS: thread t owns column c = t % 64 of
-// the rows 4 q + t / 64 (q = 0..15).  Per step k only the pivot row and the pivot column travel through LDS (double-buffered:
-// one barrier per step); everything else is 16 FMAs on registers.  The k loop stays ROLLED -- unrolled 64 times the kernel is
-// 6800 instructions of straight-line code that runs once, i.e. one instruction-cache miss per 8 instructions (measured: 57 us
-// per tile) -- so "the register that holds row k" is picked by a select chain.  1 / pivot is a v_rcp_f64 + two Newton steps
-// instead of the full IEEE division sequence: the pivot chain is the critical path of the whole elimination.
-// The tile is in M (row stride INV_LD) on entry, the inverse in M on exit; X is 2 x 128 doubles.
-__device__ __forceinline__ void invert64(double* __restrict__ M, double* __restrict__ X, int* __restrict__ singular) {
-    const int t = threadIdx.x, c = t & 63, w = t >> 6;
-    double a[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = M[(4 * q + w) * INV_LD + c];
+// Inverse of a 64 x 64 tile without pivoting, as a 4 x 4 BLOCK Gauss-Jordan elimination with 16 x 16 blocks: the pivot block is
+// inverted by ONE wave in registers (lane l holds column l % 16 of the rows l / 16 + 4 q, i.e. the f64 MFMA C / D layout; the
+// pivot row and column travel by ds_bpermute, no barrier: 0.2 us per scalar pivot), the 15 block products of a block step run
+// on v_mfma_f64_16x16x4_f64, 4 barriers per block step.  Measured (scripts/r4_micro/gj_tile_bench.hip): the scalar version this
+// replaces -- the tile in the registers of 4 waves, pivot row / column through LDS, one barrier per pivot -- took 42 us per tile,
+// 23 us of it instruction issue (one wave per SIMD) and 18 us LDS exchange + barrier; the pivot chain of the diagonal tiles is
+// the critical path of the whole elimination (30 tiles at N = 1900).
+// The tile is in M (row stride INV_LD) on entry, the inverse in M on exit; X: 7 scratch blocks of 16 x SB_LD doubles.
+constexpr int SB_LD = 17;
+
+__device__ __forceinline__ void inv16_wave(double (&a)[4], int l, int* __restrict__ singular) {
+    const int c = l & 15, g = l >> 4;
 #pragma unroll 1
-    for (int k = 0; k < GB; ++k) {
-        double* __restrict__ prow = X + (k & 1) * 128;              // pivot row k (unscaled), 64 entries
-        double* __restrict__ pcol = prow + 64;                       // pivot column k, 64 entries
-        const int kq = k >> 2;
-        if (w == (k & 3)) {                                          // the wave that owns row k
-            double sel = a[0];
+    for (int k = 0; k < 16; ++k) {
+        const int kq = k >> 2, kg = k & 3;
+        double sel = a[0];
 #pragma unroll
-            for (int q = 1; q < 16; ++q) sel = (q == kq) ? a[q] : sel;
-            prow[c] = sel;
-        }
-        if (c == k) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) pcol[4 * q + w] = a[q];
-        }
-        __syncthreads();
-        const double piv = prow[k];
-        if (t == 0 && !(fabs(piv) > 1e-300 && fabs(piv) < 1e300)) *singular = 1;
+        for (int q = 1; q < 4; ++q) sel = (q == kq) ? a[q] : sel;
+        const double prow = __shfl(sel, 16 * kg + c);              // M[k][c]
+        const double piv = __shfl(sel, 16 * kg + k);               // M[k][k]
+        if (l == 0 && !(fabs(piv) > 1e-300 && fabs(piv) < 1e300)) *singular = 1;
         double d = __builtin_amdgcn_rcp(piv);
         d = d * (2.0 - piv * d);
         d = d * (2.0 - piv * d);
-        const double pk = (c == k) ? d : prow[c] * d;                // new entry of row k in this thread's column
-        const bool mine = (w == (k & 3));
+        const double pk = (c == k) ? d : prow * d;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const double f = pcol[4 * q + w];
+        for (int q = 0; q < 4; ++q) {
+            const double f = __shfl(a[q], 16 * g + k);             // M[g + 4 q][k]
             const double upd = (c == k) ? -f * d : a[q] - f * pk;
-            a[q] = (mine && q == kq) ? pk : upd;
+            a[q] = (g == kg && q == kq) ? pk : upd;
         }
     }
-    __syncthreads();
+}
+// acc (C layout: row l / 16 + 4 reg, column l % 16) += sgn * A B; A, B: 16 x 16 blocks in LDS with row strides lda / ldb
+__device__ __forceinline__ d4_t mma16(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, d4_t acc,
+                                      double sgn, int l) {
+    const int c = l & 15, g = l >> 4;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) M[(4 * q + w) * INV_LD + c] = a[q];
-    __syncthreads();
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const double a = sgn * A[c * lda + g + 4 * s4];
+        const double b = B[(g + 4 * s4) * ldb + c];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ d4_t ld_c(const double* __restrict__ X, int ld, int l) {
+    const int c = l & 15, g = l >> 4;
+    return d4_t{X[g * ld + c], X[(g + 4) * ld + c], X[(g + 8) * ld + c], X[(g + 12) * ld + c]};
+}
+__device__ __forceinline__ void st_c(double* __restrict__ X, int ld, d4_t v, int l) {
+    const int c = l & 15, g = l >> 4;
+    X[g * ld + c] = v[0]; X[(g + 4) * ld + c] = v[1]; X[(g + 8) * ld + c] = v[2]; X[(g + 12) * ld + c] = v[3];
+}
+__device__ __forceinline__ void invert64(double* __restrict__ M, double* __restrict__ X, int* __restrict__ singular) {
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    double* __restrict__ Dinv = X;
+    for (int kb = 0; kb < 4; ++kb) {
+        if (w == 0) {                                              // the pivot block: one wave, registers
+            const d4_t v = ld_c(M + (16 * kb) * INV_LD + 16 * kb, INV_LD, l);
+            double a[4] = {v[0], v[1], v[2], v[3]};
+            inv16_wave(a, l, singular);
+            st_c(Dinv, SB_LD, d4_t{a[0], a[1], a[2], a[3]}, l);
+        }
+        __syncthreads();
+        // R_j = D^-1 M[kb][j] (3 blocks), Cn_i = -M[i][kb] D^-1 (3 blocks): wave w takes products w and w + 4
+        for (int pidx = w; pidx < 6; pidx += 4) {
+            const int o = pidx % 3;
+            const int idx = o + (o >= kb ? 1 : 0);                 // the o-th block index != kb
+            d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+            if (pidx < 3) {
+                acc = mma16(Dinv, SB_LD, M + (16 * kb) * INV_LD + 16 * idx, INV_LD, acc, 1.0, l);
+                st_c(X + (1 + o) * 16 * SB_LD, SB_LD, acc, l);
+            } else {
+                acc = mma16(M + (16 * idx) * INV_LD + 16 * kb, INV_LD, Dinv, SB_LD, acc, -1.0, l);
+                st_c(X + (4 + o) * 16 * SB_LD, SB_LD, acc, l);
+            }
+        }
+        __syncthreads();
+        // M[i][j] -= M[i][kb] R_j for i, j != kb: 9 products
+        for (int pidx = w; pidx < 9; pidx += 4) {
+            const int oi = pidx / 3, oj = pidx % 3;
+            const int i = oi + (oi >= kb ? 1 : 0), j = oj + (oj >= kb ? 1 : 0);
+            double* __restrict__ Mij = M + (16 * i) * INV_LD + 16 * j;
+            d4_t acc = ld_c(Mij, INV_LD, l);
+            acc = mma16(M + (16 * i) * INV_LD + 16 * kb, INV_LD, X + (1 + oj) * 16 * SB_LD, SB_LD, acc, -1.0, l);
+            st_c(Mij, INV_LD, acc, l);
+        }
+        __syncthreads();
+        // block row kb <- R_j, block column kb <- Cn_i, pivot block <- D^-1
+        for (int e = t; e < 7 * 256; e += 256) {
+            const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            const double v = X[blk * 16 * SB_LD + r * SB_LD + c];
+            if (blk == 0) M[(16 * kb + r) * INV_LD + 16 * kb + c] = v;
+            else if (blk < 4) { const int o = blk - 1, j = o + (o >= kb ? 1 : 0); M[(16 * kb + r) * INV_LD + 16 * j + c] = v; }
+            else { const int o = blk - 4, i = o + (o >= kb ? 1 : 0); M[(16 * i + r) * INV_LD + 16 * kb + c] = v; }
+        }
+        __syncthreads();
+    }
 }
 
 // write the inverse held in M0 as Pinv (row-major 64 x 64) and PinvT
@@ -131,7 +183,7 @@ __device__ __forceinline__ void store_pinv(const double* __restrict__ M0, double
 // first pivot block: P^-1 of A[0, 0]
 __global__ __launch_bounds__(256) void k_gj_first(int Np, const double* __restrict__ A, double* __restrict__ Pinv,
                                                   double* __restrict__ PinvT, int* __restrict__ singular) {
-    __shared__ double M[GB * INV_LD + 256];
+    __shared__ double M[GB * INV_LD + 7 * 16 * SB_LD];
     tile_to_lds(M, INV_LD, A, Np);
     __syncthreads();
     invert64(M, M + GB * INV_LD, singular);

@@ -7,6 +7,7 @@
 // (tet, a, b) -> block-slot relation is resolved ONCE and inverted, so the
 // device never searches and never needs atomics.
 #include <algorithm>
+#include <complex>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
@@ -380,5 +381,63 @@ extern "C" int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, co
         for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
             if (colind[k] >= n_owned) { rows_out[m++] = i; break; }
     *n_out = m;
+    return SNS_OK;
+}
+
+// Eigenvalues of a small real upper-Hessenberg matrix (row-major n x n; entries below the first subdiagonal are ignored): shifted
+// QR with Givens rotations in complex arithmetic (Wilkinson shift, deflation, an exceptional shift every 10th sweep).  Serves the
+// Ritz values of the short Arnoldi process that bounds the smoother damping (sns_api.hip: arnoldi_ritz); n <= 32.
+extern "C" int sns_host_hessenberg_eigs(int n, const double* H, double* re, double* im) {
+    if (n <= 0 || n > 32 || !H || !re || !im) return SNS_E_ARG;
+    typedef std::complex<double> cd;
+    std::vector<cd> A((size_t)n * n, cd(0.0, 0.0));
+    for (int i = 0; i < n; ++i)
+        for (int j = std::max(0, i - 1); j < n; ++j) A[(size_t)i * n + j] = cd(H[(size_t)i * n + j], 0.0);
+    auto at = [&](int i, int j) -> cd& { return A[(size_t)i * n + j]; };
+    std::vector<cd> ev((size_t)n), cs((size_t)n), sn((size_t)n);
+    int hi = n - 1, iter = 0;
+    while (hi >= 0) {
+        if (hi == 0) { ev[0] = at(0, 0); break; }
+        int lo = hi;
+        while (lo > 0) {
+            double sc = std::abs(at(lo - 1, lo - 1)) + std::abs(at(lo, lo));
+            if (sc == 0.0) sc = 1.0;
+            if (std::abs(at(lo, lo - 1)) < 1e-15 * sc) { at(lo, lo - 1) = 0.0; break; }
+            --lo;
+        }
+        if (lo == hi) { ev[(size_t)hi] = at(hi, hi); --hi; iter = 0; continue; }
+        if (++iter > 300) {                                  // no convergence (never seen): the diagonal as it stands
+            for (int i = lo; i <= hi; ++i) ev[(size_t)i] = at(i, i);
+            hi = lo - 1; iter = 0;
+            continue;
+        }
+        const cd a = at(hi - 1, hi - 1), b = at(hi - 1, hi), c = at(hi, hi - 1), d = at(hi, hi);
+        const cd tr = a + d, det = a * d - b * c, disc = std::sqrt(tr * tr * 0.25 - det);
+        const cd m1 = tr * 0.5 + disc, m2 = tr * 0.5 - disc;
+        cd mu = std::abs(m1 - d) < std::abs(m2 - d) ? m1 : m2;
+        if (iter % 10 == 0) mu += cd(std::abs(at(hi, hi - 1)), 0.5 * std::abs(at(hi, hi - 1)));      // exceptional shift
+        for (int i = lo; i <= hi; ++i) at(i, i) -= mu;
+        for (int k = lo; k < hi; ++k) {                      // H - mu I = Q R
+            const cd x = at(k, k), y = at(k + 1, k);
+            const double r = std::sqrt(std::norm(x) + std::norm(y));
+            const cd cc = r == 0.0 ? cd(1.0, 0.0) : x / r, ss = r == 0.0 ? cd(0.0, 0.0) : y / r;
+            cs[(size_t)k] = cc; sn[(size_t)k] = ss;
+            for (int j = k; j <= hi; ++j) {
+                const cd t1 = at(k, j), t2 = at(k + 1, j);
+                at(k, j) = std::conj(cc) * t1 + std::conj(ss) * t2;
+                at(k + 1, j) = -ss * t1 + cc * t2;
+            }
+        }
+        for (int k = lo; k < hi; ++k) {                      // R Q + mu I
+            const cd cc = cs[(size_t)k], ss = sn[(size_t)k];
+            for (int i = lo; i <= std::min(k + 1, hi); ++i) {
+                const cd t1 = at(i, k), t2 = at(i, k + 1);
+                at(i, k) = t1 * cc + t2 * ss;
+                at(i, k + 1) = -t1 * std::conj(ss) + t2 * std::conj(cc);
+            }
+        }
+        for (int i = lo; i <= hi; ++i) at(i, i) += mu;
+    }
+    for (int i = 0; i < n; ++i) { re[i] = ev[(size_t)i].real(); im[i] = ev[(size_t)i].imag(); }
     return SNS_OK;
 }

@@ -85,7 +85,8 @@ struct Level {
     // aggregate-block Jacobi smoother (amg_block_smooth, csrc/sns_block.hip): member rows of every aggregate padded to 8 slots
     // (-1: none), built with the hierarchy; the aggregates' inverse diagonal blocks (fp32, 1024 floats each) per numeric setup
     int32_t* blk_rows = nullptr;
-    int32_t n_blk = 0;                   // aggregates covered (= nc)
+    int32_t* blk_of = nullptr;           // node -> its smoother block (-1: ghost node)
+    int32_t n_blk = 0;                   // smoother blocks (= nc, plus one per aggregate of more than 8 nodes)
     float* binv32 = nullptr;
     // work vectors (4*n doubles)
     double *x = nullptr, *b = nullptr, *r = nullptr;
@@ -102,6 +103,7 @@ struct Level {
     double omega = 0.8;
     double lambda_max = 0.0;
     double omega_checked = 0.0;          // damping that passed the growth test at the last fresh estimate
+    double ritz_limit = 0.0;             // stability limit of the damping from the Ritz values of S A (amg_ritz_limit; 0 = not estimated)
 };
 
 void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc);

@@ -127,8 +127,8 @@ __global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t*
 __global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const float4* binv, const double* bvec, double omega, double* z);
 __global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                const uint8_t* free_mask, const double* r, double* bc, const float4* binv_c, double omega_c, double* z_c);
-__global__ void k_binv(int32_t nagg, const int32_t* m_ptr, const int32_t* m_idx, const int32_t* agg, const int32_t* rowptr,
-                       const int32_t* colind, const double* vals, float4* binv, int* singular);
+__global__ void k_binv(int32_t nblk, const int32_t* blk_rows, const int32_t* blk_of, const int32_t* rowptr, const int32_t* colind,
+                       const double* vals, float4* binv, int* singular);
 __global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
 __global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
 __global__ void k_fill_pattern(int64_t n, double* x);

@@ -336,6 +336,14 @@ class FlowProblem:
         check(self.lib.sns_get_hierarchy(self.h, C.byref(nl), rows, blocks, nu, om))
         return [dict(rows=rows[l], blocks=blocks[l], sweeps=nu[l], omega=om[l]) for l in range(nl.value)]
 
+    def cycle(self):
+        """The V-cycle as run: per level dict(kind, pre, post) -- kind 0 nodal-block Jacobi, 1 aggregate-block Jacobi, 2 / 3 dense
+        direct solve (one-workgroup / blocked Gauss-Jordan), 4 sweeps only (sns_get_cycle)."""
+        nl = C.c_int32()
+        kind, pre, post = (C.c_int32 * 16)(), (C.c_int32 * 16)(), (C.c_int32 * 16)()
+        check(self.lib.sns_get_cycle(self.h, C.byref(nl), kind, pre, post))
+        return [dict(kind=kind[l], pre=pre[l], post=post[l]) for l in range(nl.value)]
+
     def reset_timings(self):
         check(self.lib.sns_reset_timings(self.h))
 

@@ -73,17 +73,14 @@ def _oracle_cycle(P, mask, r, block, dense_rows):
     rp, ci = rp.cpu().numpy(), ci.cpu().numpy()
     G = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(len(rp) - 1, len(rp) - 1))
     hier = P.hierarchy()
+    cyc = P.cycle()                                              # smoother kind and sweeps per level, as the GPU runs them
     nl = len(hier)
-    blk = tuple(range(1, nl - 1)) if block else ()
+    blk = tuple(l for l, c in enumerate(cyc) if c["kind"] == 1)
+    assert blk == (tuple(range(1, nl - 1)) if block else ()), cyc
+    assert cyc[-1]["kind"] == (3 if dense_rows else 2), cyc
     lv = AC.build(A, ~mask.astype(bool), dense_rows=dense_rows, block_levels=blk, graph=G)
     assert [L.n for L in lv] == [h["rows"] for h in hier], ([L.n for L in lv], hier)
-    sweeps = []
-    for l, h in enumerate(hier):
-        nu = h["sweeps"]
-        if l == 1 and nl > 2:                                   # single-GPU level 1: one sweep before, more after
-            sweeps.append((1, P.options.amg_bnu_l1) if block else (1, nu + 2))
-        else:
-            sweeps.append((nu, nu))
+    sweeps = [(c["pre"], c["post"]) for c in cyc]
     om = [h["omega"] for h in hier]
     return AC.cycle(lv, 0, r, sweeps, om), lv
 

@@ -421,7 +421,7 @@ def test_entry_point_drivers(gpu, tmp_path, monkeypatch, capsys):
 
 
 @pytest.mark.parametrize("nranks,kind", [(2, "duct"), (3, "duct"), (4, "cavity"), (6, "slab"), (4, "duct-rep"),
-                                         (5, "cavity-rep")])
+                                         (5, "cavity-rep"), (4, "duct-rep-dense")])
 def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
     """The element-partitioned solver (distributed AMG hierarchy with cross-rank couplings, halo
     exchanges on every level, global dense coarsest solve, all-reduced dots) run as N threads on one
@@ -434,7 +434,10 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
         monkeypatch.setenv("SNS_TEAM_OVERLAP", "1")
     # "-rep": a small coarsest size forces a REPLICATED tail of the hierarchy from level 1 on (every rank holds the
     # global level-1 operator, all-gathered values, and cycles the levels below redundantly without exchanges)
-    kw = dict(amg_coarse_size=24, amg_replicate_rows=1 << 20) if kind.endswith("-rep") else {}
+    # ("-rep": the tail coarsened down to <= 24 nodes as in rounds 1-3, amg_dense_rows = 0; "-rep-dense": round 4's default, the
+    # replicated level 1 -- 245 rows -- is itself the coarsest level and solved by the blocked Gauss-Jordan inverse on every rank)
+    kw = (dict(amg_coarse_size=24, amg_replicate_rows=1 << 20, amg_dense_rows=0) if kind.endswith("-rep") else
+          dict(amg_replicate_rows=1 << 20) if kind.endswith("-rep-dense") else {})
     if kind.startswith("duct"):
         m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
         mask, g = B.duct_bcs(m).flatten()
@@ -501,8 +504,10 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
         assert (r.its, n.ksp_its) == (outs[0][2].its, outs[0][4].ksp_its)      # every rank took the same decisions
     assert rel(Ug, Us) < 1e-6 and rel(wg, ws) < 1e-8
     assert outs[0][2].its <= 2 * rs.its + 4                                   # coarse correction stays global
-    if kw:
+    if kind.endswith("-rep"):
         assert outs[0][5] >= 3                                                # fine, distributed level 1, replicated tail
+    if kind.endswith("-rep-dense"):
+        assert outs[0][5] == 2                                                # fine + the replicated, directly solved level 1
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
@@ -1154,7 +1159,18 @@ def test_unstructured_delaunay_mesh_iteration_bound(gpu):
         H = P.hierarchy()
         assert len(H) == P.timings().amg_levels and H[0]["rows"] == m.num_nodes and H[0]["blocks"] == P.sizes()["nnzb"]
         assert all(a["rows"] > 3 * b["rows"] for a, b in zip(H, H[1:]))
-        assert [L["sweeps"] for L in H[:3]] == [1, 4, 6] and all(L["sweeps"] == 2 for L in H[3:-1]) and H[-1]["sweeps"] == 0
+        # sweeps per half cycle as sns_get_hierarchy reports them: nodal-block levels 1 / 4 / 6 / 2 (fine, level 1, level 2, deeper),
+        # aggregate-block levels (round 4: the latency-bound ones) amg_bnu_l2 = 3 on levels 1-2 and amg_bnu_deep = 1 below
+        # (the unstructured mesh is in the first tier of amg_nu_scale_with_size: + 2 nodal resp. + 1 aggregate-block sweeps from level 2 on)
+        cyc = P.cycle()
+        tier = 0 if name == "structured" else 1
+        for l, (L, c) in enumerate(zip(H[:-1], cyc[:-1])):
+            if c["kind"] == 0:
+                want = [1, 4, 6 + 2 * tier][l] if l < 3 else 2 + 2 * tier
+            else:
+                want = 3 + (tier if l == 2 else 0) if l <= 2 else 1 + tier
+            assert L["sweeps"] == want, (name, l, H, cyc)
+        assert cyc[0]["kind"] == 0 and H[-1]["sweeps"] == 0 and cyc[-1]["kind"] in (2, 3)
         assert all(0.3 < L["omega"] <= 0.8 for L in H)
         ratio = H[0]["rows"] / H[1]["rows"]
         assert (7.0 < ratio <= 8.0) if name == "structured" else (4.0 < ratio < 6.0)
@@ -1257,7 +1273,21 @@ def test_damping_backoff_rescues_a_failed_linear_solve(gpu):
     iterations is never retried, and with amg_retry_damping = 0 the failure is reported as PETSc would."""
     from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
     m = M.duct_mesh((120, 30, 30), 4.0, jitter=0.2)
-    P = gpu(m, B.duct_bcs(m), reynolds=200.0, ksp_max_it=1500)
+    # Round 4 (VERDICT r3 item 3): the hard case converges at the FIRST attempt, without the retry, under the defaults -- the
+    # aggregate-block smoother of the coarse levels -- and also with round 3's nodal blocks once the damping is capped by the
+    # stability limit of the dominant Ritz values (amg_ritz_limit; the failing level was level 1: 1 + 6 sweeps at w = 0.68 against
+    # a limit of 0.45 -- 0.50 from the GPU's 8 Arnoldi steps).  The retry mechanics below are exercised on round 3's estimate.
+    for opts in (dict(), dict(amg_block_smooth=0, amg_dense_rows=0)):
+        Pd = gpu(m, B.duct_bcs(m), reynolds=200.0, ksp_max_it=600, amg_retry_damping=0, **opts)
+        Ud, rd = Pd.stokes_solve()
+        wd, nd_ = Pd.newton_solve(Ud.clone())
+        cd = Pd.counters()
+        print(f"  first attempt, no retry, {opts or 'defaults'}: Newton {nd_.its} its, {nd_.ksp_its} ksp its, reason {nd_.reason}; "
+              f"omega {[round(h['omega'], 3) for h in Pd.hierarchy()]}")
+        assert rd.reason > 0 and nd_.reason > 0 and nd_.its <= 6 and cd["damping_retries"] == 0
+        assert float(Pd.residual(wd, "ns").norm()) < 1e-8
+        Pd.close()
+    P = gpu(m, B.duct_bcs(m), reynolds=200.0, ksp_max_it=1500, amg_block_smooth=0, amg_dense_rows=0, amg_ritz_limit=0)
     U, r = P.stokes_solve()
     assert r.reason > 0
     P.reset_timings()

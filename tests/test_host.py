@@ -611,3 +611,24 @@ def test_extruded_slab_mesh_is_conforming_and_carries_the_2d_tags():
     assert np.allclose(g[4 * nd], 4 * 0.3 * y * (0.41 - y) / 0.41 ** 2) and g[4 * nd].max() > 0.29
     out_only = np.setdiff1d(m3.facet_nodes(tg["outlet"]), m3.facet_nodes(tg["walls"]))
     assert not mask[4 * out_only].any() and not mask[4 * out_only + 1].any()       # natural outlet
+
+
+def test_hessenberg_eigenvalues_match_numpy():
+    """sns_host_hessenberg_eigs (shifted complex QR on a small upper-Hessenberg matrix): the Ritz values behind the damping limit
+    of amg_ritz_limit.  Random matrices of every size the Arnoldi process produces, incl. reducible ones; vs numpy.linalg.eigvals."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 8, 10, 17, 32):
+        for trial in range(10):
+            H = np.triu(rng.normal(size=(n, n)), -1)
+            if trial % 3 == 0 and n > 2:
+                H[n // 2, n // 2 - 1] = 0.0
+            re, im = np.zeros(n), np.zeros(n)
+            Hc = np.ascontiguousarray(H)
+            assert lib.sns_host_hessenberg_eigs(n, Hc.ctypes.data, re.ctypes.data, im.ctypes.data) == 0
+            ref = np.linalg.eigvals(H)
+            ev = re + 1j * im
+            assert max(np.min(np.abs(ref - e)) for e in ev) < 1e-8 * max(1.0, np.abs(ref).max())
+            assert max(np.min(np.abs(ev - e)) for e in ref) < 1e-8 * max(1.0, np.abs(ref).max())
+    assert lib.sns_host_hessenberg_eigs(0, None, None, None) != 0

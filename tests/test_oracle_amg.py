@@ -25,13 +25,16 @@ def test_aggregate_block_inverse_inverts_the_aggregates_diagonal_blocks():
     Ab.sort_indices()
     agg, nc = _lib.host_aggregate(Ab.indptr, Ab.indices, None, 8)
     S = AC.aggregate_block_inverse(A, agg, nc)
-    for I in (0, nc // 2, nc - 1):
-        dofs = (4 * np.flatnonzero(agg == I)[:, None] + np.arange(4)[None]).ravel()
+    blk_of, nb = AC.smoother_blocks(agg, nc)
+    assert nb >= nc and np.bincount(blk_of).max() <= 8             # aggregates, the oversized ones split into chunks of 8
+    assert np.all(agg[np.argsort(blk_of, kind="stable")][:-1] <= agg[np.argsort(blk_of, kind="stable")][1:])   # never across aggregates
+    for I in (0, nb // 2, nb - 1):
+        dofs = (4 * np.flatnonzero(blk_of == I)[:, None] + np.arange(4)[None]).ravel()
         blk = A[dofs][:, dofs].toarray()
         assert np.allclose(S[dofs][:, dofs].toarray() @ blk, np.eye(len(dofs)), atol=1e-10)
-    # block diagonal: nothing couples two aggregates
+    # block diagonal: nothing couples two blocks
     rows, cols = S.nonzero()
-    assert np.all(agg[rows // 4] == agg[cols // 4])
+    assert np.all(blk_of[rows // 4] == blk_of[cols // 4])
     D = AC.nodal_block_inverse(A, n)
     assert np.allclose((D @ A).tobsr((4, 4)).diagonal(), 1.0)
 
