@@ -170,7 +170,7 @@ typedef struct {
     int    amg_bnu_l1;      /* sweeps after the coarse-grid correction on level 1 under amg_block_smooth (3; one sweep before it);
                                a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*) */
     int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (3) */
-    int    amg_bnu_deep;    /* ... and on levels >= 3 (1).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
+    int    amg_bnu_deep;    /* ... and on levels >= 3 (2: the nodal blocks' count, with the stronger smoother).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
     int    amg_ritz_limit;  /* 1 (default): on every level that runs 3 or more sweeps per cycle the damping is also capped by the
                                STABILITY limit of the dominant Ritz values of S A (S = the smoother's block inverse) from 8 Arnoldi
                                steps, w <= min 2 Re(theta) / |theta|^2: the power iteration of rounds 1-3 sees |lambda|max only,

@@ -100,6 +100,7 @@ struct sns_ctx {
     int pc_setups = 0;
     // hipGraph of the launch-bound coarse part of the V-cycle (levels >= graph_level; serial runs only)
     hipStream_t cap_stream = nullptr;
+    hipStream_t gj_stream = nullptr;              // second stream of the dense coarsest level's elimination (bulk updates beside the pivot chain)
     hipGraphExec_t coarse_graph = nullptr;
     std::vector<double> graph_sig;                // (omega per level, nu, nu_coarse, f32) the graph was captured with
     bool graph_disabled = false;
@@ -135,6 +136,9 @@ struct sns_ctx {
     bool team_overlap = false;                       // SNS_TEAM_OVERLAP: the team transport takes the two-stream path too (tests)
     double* arn_V = nullptr;                          // Arnoldi basis of the damping estimate, 9 vectors of the largest level >= ... asked for
     size_t arn_cap = 0;
+    bool first_sweep_done = false;                   // the V-cycle's fine-level first sweep was done by the Krylov kernel that wrote its input
+    bool r3_estimates = false;                       // SNS_R3_SPECTRAL_ESTIMATE (tests of the retry path): round 3's policy -- spectral
+                                                     // estimates every 4th setup whatever the operator (first Jacobians on the Stokes estimate)
     double damping_backoff = 1.0;                    // < 1 after a failed AMG-preconditioned solve: all level dampings scaled (krylov())
     int64_t ctr_retries = 0;                         // damping retries since sns_reset_timings
     int last_first_reason = 0;                       // reason of the FIRST attempt of the last solve (0 = no retry happened)
@@ -208,7 +212,7 @@ void time_collect(sns_ctx* h) {
 
 // finish a two-stage reduction locally: partial[nblocks][nred] -> dst_dev[0..nred)
 void reduce_local(sns_ctx* h, int nblocks, int nred, double* dst_dev) {
-    if (nblocks > 40000 && nred <= 8) {
+    if (nblocks > 8192 && nred <= 8) {
         // the fused SpMV+dot leaves one partial per 32 rows (54 k at 10 M tets): a single workgroup needs ~40 us
         // for that, 2048-wide chunks on many CUs first ~5 us
         const int nchunks = (nblocks + 2047) / 2048;
@@ -240,7 +244,8 @@ int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
     }
     const double* src = h->partial;
     int nb = nblocks;
-    if (nblocks > 40000) {                       // (as reduce_local: 2048-wide chunks on many CUs first)
+    if (nblocks > 8192) {                        // (as reduce_local: 2048-wide chunks on many CUs first; one workgroup over 27 k
+                                                 // partials -- the slab share -- was measured at 29 us against 4.6 + 4.8 for the two stages)
         const int nchunks = (nblocks + 2047) / 2048;
         if (nchunks <= 4096) {
             hipLaunchKernelGGL(k_reduce_chunks, dim3(nchunks, NRED), dim3(256), 0, h->stream, nblocks, NRED, h->partial, h->partial2);
@@ -1364,7 +1369,7 @@ int pc_setup(sns_ctx* h) {
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     const int nl = (h->opt.pc_type == SNS_PC_AMG) ? (int)h->levels.size() : 1;
     bool any_block = false;
-    const bool new_operator = h->matrix_form != h->est_form || h->opt.reynolds != h->est_re;
+    const bool new_operator = !h->r3_estimates && (h->matrix_form != h->est_form || h->opt.reynolds != h->est_re);
     for (int l = 0; l < nl; ++l) {
         Level& L = h->levels[l];
         const int32_t rows = L.n_owned;
@@ -1518,7 +1523,9 @@ int pc_setup(sns_ctx* h) {
             hipLaunchKernelGGL(k_bsr_to_dense_ld, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->stream, L.nnzb,
                                h->slot_row[l], L.colind, L.vals, Np, L.dense_gj);
             if (Np > N) hipLaunchKernelGGL(k_dense_pad_diag, dim3((Np - N + 255) / 256), dim3(256), 0, h->stream, N, Np, L.dense_gj);
-            dense_gj_inverse(h->stream, Np, L.dense_gj, L.dense_work, h->d_sing);
+            if (!h->gj_stream && !std::getenv("SNS_GJ_ONE_STREAM") &&
+                hipStreamCreateWithFlags(&h->gj_stream, hipStreamNonBlocking) != hipSuccess) h->gj_stream = nullptr;
+            dense_gj_inverse(h->stream, h->gj_stream, Np, L.dense_gj, L.dense_work, h->d_sing);
             const int64_t nn = (int64_t)Np * Np;
             hipLaunchKernelGGL(k_dense_to_f32, dim3((unsigned)((nn / 4 + 255) / 256)), dim3(256), 0, h->stream, nn, L.dense_gj,
                                L.dense_x32);
@@ -1766,7 +1773,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     }
     // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read (already done
     // by the restriction kernel of the level above where restrict_fuses_first says so)
-    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1))) launch_first_sweep(h, l, L, rows, b, om, cur);
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1)) && !(l == 0 && h->first_sweep_done))
+        launch_first_sweep(h, l, L, rows, b, om, cur);
+    if (l == 0) h->first_sweep_done = false;
     for (int s = 1; s < nu_pre; ++s) {
         if (sx) SNS_TRY(exchange_level(h, l, cur));
         launch_sweep(h, l, L, rows, cur, oth, b, om);
@@ -1961,6 +1970,18 @@ int dot(sns_ctx* h, const double* x, const double* y, double* out) {
     return SNS_OK;
 }
 
+// Can the Krylov kernel that writes the preconditioner's input also do the V-cycle's first fine-level sweep z = w D^-1 (input)
+// (k_bicg_s_first / k_bicg_xrp_first: one dependent launch and one read of the input less per cycle)?  Returns the buffer the
+// cycle of pc_apply(., zdst) starts from, or nullptr.
+double* fused_first_sweep_target(sns_ctx* h, double* zdst) {
+    if (h->opt.pc_type != SNS_PC_AMG || h->levels.size() < 2 || h->opt.amg_fine_cycle != 0 || !h->pc_ready) return nullptr;
+    const Level& L = h->levels[0];
+    if (block_active(h, 0) || lp_format(h, L) == 0 || !L.dinv32 || L.n_owned <= 0) return nullptr;
+    if (h->rep_level == 1) return nullptr;                       // level 0 is only the source of the replicated copy
+    double* x = (h->n > h->n_owned) ? h->levels[0].x : zdst;     // (pc_apply cycles a partitioned handle in its own buffer)
+    return cycle_start_buffer(h, 0, x);
+}
+
 // ---- BiCGStab (right-preconditioned; the recurrences of oracle/solve.py:bicgstab_bj) ----
 // Latency-lean formulation: rho / alpha / omega / beta live on the device (sc[]), the vector kernels read them
 // there, and the three reductions of the textbook iteration are two -- <rhat, v>, then ONE pass for
@@ -2017,7 +2038,13 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
         double best_rn = rn;
         int best_it = 0;
         for (its = 1;; ++its) {
-            hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
+            if (double* z1 = fused_first_sweep_target(h, sh)) {
+                hipLaunchKernelGGL(k_bicg_s_first, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s, h->levels[0].dinv32,
+                                   h->levels[0].omega, z1);
+                h->first_sweep_done = true;
+            } else {
+                hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
+            }
             SNS_TRY(pc_apply(h, s, sh));
             SNS_TRY(op_apply(h, sh, t));
             hipLaunchKernelGGL(k_bicg_dots5, dim3(g), dim3(256), 0, h->stream, nd, s, t, rhat, h->partial);
@@ -2028,7 +2055,13 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             // rides on the x / r update (k_bicg_xrp)
             const bool spec = its < o.ksp_max_it;
             if (spec) {
-                hipLaunchKernelGGL(k_bicg_xrp, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p);
+                if (double* z1 = fused_first_sweep_target(h, ph)) {
+                    hipLaunchKernelGGL(k_bicg_xrp_first, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p,
+                                       h->levels[0].dinv32, h->levels[0].omega, z1);
+                    h->first_sweep_done = true;
+                } else {
+                    hipLaunchKernelGGL(k_bicg_xrp, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p);
+                }
                 SNS_TRY(first_half(true));
             } else {
                 hipLaunchKernelGGL(k_bicg_xr, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, x, r);
@@ -2409,7 +2442,7 @@ void sns_default_options(sns_options* o) {
     o->amg_block_smooth = 1;
     o->amg_bnu_l1 = 3;
     o->amg_bnu_l2 = 3;
-    o->amg_bnu_deep = 1;
+    o->amg_bnu_deep = 2;
     o->amg_ritz_limit = 1;
     o->amg_block_max_rows = 8192;
 }
@@ -2552,6 +2585,7 @@ static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_te
     HIP_TRY(hipDeviceSynchronize());
     h->tm = sns_timings{};
     h->graph_disabled = std::getenv("SNS_NO_GRAPH") != nullptr;
+    h->r3_estimates = std::getenv("SNS_R3_SPECTRAL_ESTIMATE") != nullptr;
     h->pattern.reset(new HostPattern(std::move(P)));
     *out = h.release();
     return SNS_OK;
@@ -2603,6 +2637,7 @@ int sns_destroy(sns_handle h) {
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
     if (h->coarse_graph) (void)hipGraphExecDestroy(h->coarse_graph);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->gj_stream) (void)hipStreamDestroy(h->gj_stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -3014,7 +3049,15 @@ int sns_dense_inverse(int device, int32_t N, const double* A, double* Ainv) {
     HIP_TRY(hipMemcpy2D(W, (size_t)Np * sizeof(double), A, (size_t)N * sizeof(double), (size_t)N * sizeof(double), N,
                         hipMemcpyDeviceToDevice));
     if (Np > N) hipLaunchKernelGGL(k_dense_pad_diag, dim3((Np - N + 255) / 256), dim3(256), 0, nullptr, N, Np, W);
-    dense_gj_inverse(nullptr, Np, W, work, sing);
+    hipStream_t side = nullptr;
+    if (!std::getenv("SNS_GJ_ONE_STREAM")) (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    HIP_TRY(hipDeviceSynchronize());                      // (the null stream does not order a non-blocking side stream)
+    hipStream_t mainst = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&mainst, hipStreamNonBlocking));
+    dense_gj_inverse(mainst, side, Np, W, work, sing);
+    HIP_TRY(hipStreamSynchronize(mainst));
+    if (side) { HIP_TRY(hipStreamSynchronize(side)); (void)hipStreamDestroy(side); }
+    (void)hipStreamDestroy(mainst);
     HIP_TRY(hipMemcpy2D(Ainv, (size_t)N * sizeof(double), W, (size_t)Np * sizeof(double), (size_t)N * sizeof(double), N,
                         hipMemcpyDeviceToDevice));
     int hs = 0;

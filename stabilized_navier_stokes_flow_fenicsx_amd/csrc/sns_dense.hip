@@ -10,14 +10,15 @@
 //                CpT_i = A[i, p]^T     for every block row i != p          (copies: the update below works in place)
 //   k_gj_update  A[i, j] -= A[i, p] R_j;  A[i, p] = -A[i, p] P^-1;  A[p, j] = R_j;  A[p, p] = P^-1,
 //                and the workgroup of tile (p+1, p+1) inverts its freshly updated tile in LDS: the next step's P^-1.
+// The bulk of a step's update runs on a second stream beside the pivot chain (dense_gj_inverse).
 // No pivoting across blocks (and none inside: the diagonal tiles are inverted by a block Gauss-Jordan of their own, see invert64): the level
 // operators are Galerkin projections of the stabilised form, whose symmetric part is positive definite (viscous + SUPG/LSIC
 // terms on the velocity block, the PSPG Laplacian on the pressure block; Dirichlet and empty coarse dofs are identity rows), so
 // every leading principal block is nonsingular and the element growth of the elimination is bounded by the ratio of the skew
 // to the symmetric part -- 1e2..1e4 on the convection-dominated coarse levels, harmless in fp64.  A pivot that is zero or not
 // finite raises *singular, and the host falls back to the smoothed hierarchy.
-// Operands of a tile product sit in LDS "k-major" ([k][m] and [k][n], row stride 80 doubles): the 16x16x4 fragment reads --
-// lane l takes element (k0 + l / 16, 16 w + l % 16) -- then hit 32 different bank pairs per half-wave.
+// Operands of a tile product sit in LDS "k-major" ([k][m] and [k][n], row stride LDS_LD doubles), so that the 16x16x4 fragment
+// reads -- lane l takes element (k0 + l / 16, 16 w + l % 16) -- are contiguous per 16 lanes.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,7 +30,9 @@ namespace sns {
 namespace {
 
 constexpr int GB = 64;              // block size of the elimination
-constexpr int LDS_LD = 80;          // row stride of an operand tile in LDS (doubles)
+constexpr int LDS_LD = 72;          // row stride of an operand tile in LDS (doubles): two workgroups per CU (2 x 73.7 KB); 80 would be
+                                    // free of bank conflicts on the fragment reads (72: two-way on half of a half-wave's lanes) but
+                                    // leaves room for one workgroup only
 constexpr int INV_LD = 65;          // row stride of the tile being inverted
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -226,14 +229,17 @@ __global__ __launch_bounds__(256) void k_gj_panel(int Np, int p, const double* _
     }
 }
 
-// block step p, part 2: one workgroup per tile (i, j)
-__global__ __launch_bounds__(256) void k_gj_update(int Np, int p, double* __restrict__ A, const double* __restrict__ Pinv,
+// block step p, part 2: one workgroup per tile (i, j).  `part` splits the step for the two-stream schedule of dense_gj_inverse:
+// 1 = only the tiles of block row / column p + 1 (what the NEXT step's panel and pivot need: the critical path), 2 = all the
+// others, 0 = every tile.
+__global__ __launch_bounds__(256) void k_gj_update(int Np, int p, int part, double* __restrict__ A, const double* __restrict__ Pinv,
                                                    const double* __restrict__ R, const double* __restrict__ CpT,
                                                    double* __restrict__ Pinv_next, double* __restrict__ PinvT_next,
                                                    int* __restrict__ singular) {
     __shared__ double S[2 * GB * LDS_LD];                 // operand tiles; reused by the inversion of the next pivot tile
     const int nb = Np / GB;
     const int i = blockIdx.x / nb, j = blockIdx.x - i * nb;
+    if (part != 0 && ((i == p + 1 || j == p + 1) != (part == 1))) return;
     const int t = threadIdx.x;
     double* Aij = A + (int64_t)i * GB * Np + (int64_t)j * GB;
     if (i == p) {                                         // pivot block row: R_j, resp. P^-1 on the diagonal
@@ -329,19 +335,48 @@ __global__ __launch_bounds__(256) void k_dense_matvec32(int N, int Np, const flo
     if (lane == 0) y[row] = s;
 }
 
-// Enqueue the blocked Gauss-Jordan inverse of the Np x Np matrix A (Np a multiple of 64, in place).  work: 2 * 64 * Np doubles
-// (R, CpT) + 4 * 4096 doubles (P^-1 and its transpose, double-buffered over the steps).
-void dense_gj_inverse(hipStream_t s, int Np, double* A, double* work, int* singular) {
+// Enqueue the blocked Gauss-Jordan inverse of the Np x Np matrix A (Np a multiple of 64, in place) on stream s.
+// work: 4 * 64 * Np doubles (R and CpT, double-buffered over the steps) + 4 * 4096 doubles (P^-1 and its transpose, likewise).
+// The pivot chain -- update of block row / column p + 1, inversion of the next pivot tile, next panel -- is the critical path
+// (40 of the 60 us of a step at N = 1900); with a second stream `side` the bulk of every step's update runs beside it:
+//   s:    panel(p) -> [U2(p-1) done] -> U1(p): tiles of row / column p + 1, then the next pivot's inverse
+//   side: [panel(p) done] -> U2(p): every other tile
+// (U1(p) needs the tiles U2(p-1) wrote; U2(p) needs R / CpT of step p and, through the panel, U1(p-1).)  side == nullptr: one stream.
+void dense_gj_inverse(hipStream_t s, hipStream_t side, int Np, double* A, double* work, int* singular) {
     const int nb = Np / GB;
-    double* R = work;
-    double* CpT = work + (size_t)GB * Np;
-    double* P = CpT + (size_t)GB * Np;                   // [2][Pinv 4096 | PinvT 4096]
+    double* RC = work;                                    // [2][R 64 x Np | CpT 64 x Np]
+    double* P = work + (size_t)4 * GB * Np;               // [2][Pinv 4096 | PinvT 4096]
+    hipEvent_t e_panel = nullptr, e_bulk = nullptr, e_start = nullptr;
+    const bool two = side != nullptr && nb > 2 && hipEventCreateWithFlags(&e_panel, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&e_bulk, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&e_start, hipEventDisableTiming) == hipSuccess;
     hipLaunchKernelGGL(k_gj_first, dim3(1), dim3(256), 0, s, Np, A, P, P + 4096, singular);
+    if (two) {                                            // whatever `side` did before must not overtake the matrix's producers on s
+        (void)hipEventRecord(e_start, s);
+        (void)hipStreamWaitEvent(side, e_start, 0);
+    }
     for (int p = 0; p < nb; ++p) {
         double* cur = P + (size_t)(p & 1) * 8192;
         double* nxt = P + (size_t)((p + 1) & 1) * 8192;
+        double* R = RC + (size_t)(p & 1) * 2 * GB * Np;
+        double* CpT = R + (size_t)GB * Np;
         if (nb > 1) hipLaunchKernelGGL(k_gj_panel, dim3(2 * nb), dim3(256), 0, s, Np, p, A, cur + 4096, R, CpT);
-        hipLaunchKernelGGL(k_gj_update, dim3(nb * nb), dim3(256), 0, s, Np, p, A, cur, R, CpT, nxt, nxt + 4096, singular);
+        if (!two) {
+            hipLaunchKernelGGL(k_gj_update, dim3(nb * nb), dim3(256), 0, s, Np, p, 0, A, cur, R, CpT, nxt, nxt + 4096, singular);
+            continue;
+        }
+        (void)hipEventRecord(e_panel, s);
+        (void)hipStreamWaitEvent(side, e_panel, 0);
+        hipLaunchKernelGGL(k_gj_update, dim3(nb * nb), dim3(256), 0, side, Np, p, 2, A, cur, R, CpT, nxt, nxt + 4096, singular);
+        if (p > 0) (void)hipStreamWaitEvent(s, e_bulk, 0);              // U2(p - 1): recorded below in the previous round
+        hipLaunchKernelGGL(k_gj_update, dim3(nb * nb), dim3(256), 0, s, Np, p, 1, A, cur, R, CpT, nxt, nxt + 4096, singular);
+        (void)hipEventRecord(e_bulk, side);
+    }
+    if (two) {
+        (void)hipStreamWaitEvent(s, e_bulk, 0);
+        (void)hipEventDestroy(e_panel);
+        (void)hipEventDestroy(e_bulk);
+        (void)hipEventDestroy(e_start);
     }
 }
 

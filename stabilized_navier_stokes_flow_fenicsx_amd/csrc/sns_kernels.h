@@ -88,6 +88,10 @@ __global__ void k_bicg_xr(int64_t n, const double* sc, const double* ph, const d
 __global__ void k_bicg_xrp(int64_t n, const double* sc, const double* ph, const double* sh, const double* s,
                            const double* t, const double* v, double* x, double* r, double* p);
 __global__ void k_bicg_init(double* sc, const double* rr0);
+__global__ void k_bicg_s_first(int64_t n, const double* r, const double* sc, const double* v, double* s, const float* dinv32,
+                               double omega_pc, double* z);
+__global__ void k_bicg_xrp_first(int64_t n, const double* sc, const double* ph, const double* sh, const double* s, const double* t,
+                                 const double* v, double* x, double* r, double* p, const float* dinv32, double omega_pc, double* z);
 __global__ void k_multi_dot8(int64_t n, int nv, const double* V, int64_t ldv, const double* w, double* partial);
 __global__ void k_multi_axpy8(int64_t n, int nv, const double* V, int64_t ldv, const double* h, double sign,
                               double* w, double* partial);
@@ -114,8 +118,8 @@ __global__ void k_bsr_to_dense_ld(int64_t nnzb, const int32_t* slot_row, const i
 __global__ void k_dense_pad_diag(int N, int Np, double* D);
 __global__ void k_dense_to_f32(int64_t n, const double* A, float* X);
 __global__ void k_dense_matvec32(int N, int Np, const float* X, const double* b, double* y);
-void dense_gj_inverse(hipStream_t s, int Np, double* A, double* work, int* singular);
-inline size_t dense_gj_work_doubles(int Np) { return (size_t)2 * 64 * Np + 4 * 4096; }
+void dense_gj_inverse(hipStream_t s, hipStream_t side, int Np, double* A, double* work, int* singular);
+inline size_t dense_gj_work_doubles(int Np) { return (size_t)4 * 64 * Np + 4 * 4096; }
 // csrc/sns_block.hip: aggregate-block Jacobi smoother of the coarse levels
 template <int FMT>
 __global__ void k_bsweep(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,

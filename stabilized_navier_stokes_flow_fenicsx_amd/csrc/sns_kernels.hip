@@ -2272,6 +2272,21 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         s[i] = r[i] - alpha * v[i];
 }
+// s = r - alpha v together with the FIRST sweep of the V-cycle that s goes into: z = w D^-1 s on the fine level's fp32 D^-1
+// copy (what k_bjacobi32 does in a launch of its own right after: same expression on the same operands, bitwise the same z).
+// Thread i = dof i, the 4 lanes of a quad = one node, so the node's s is exchanged by DPP.  n is a multiple of 4.
+__global__ __launch_bounds__(256) void k_bicg_s_first(int64_t n, const double* __restrict__ r, const double* __restrict__ sc,
+                                                      const double* __restrict__ v, double* __restrict__ s,
+                                                      const float* __restrict__ dinv32, double omega_pc, double* __restrict__ z) {
+    const double alpha = sc[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double sv = r[i] - alpha * v[i];
+        s[i] = sv;
+        const float4 D = *reinterpret_cast<const float4*>(dinv32 + 4 * i);      // row (i % 4) of node (i / 4)'s block
+        const double s0 = quad_bcast<0>(sv), s1 = quad_bcast<1>(sv), s2 = quad_bcast<2>(sv), s3 = quad_bcast<3>(sv);
+        z[i] = omega_pc * ((double)D.x * s0 + (double)D.y * s1 + (double)D.z * s2 + (double)D.w * s3);
+    }
+}
 // ONE reduction pass for the second half of an iteration: (t.s, t.t, rhat.s, rhat.t, s.s).  omega = t.s / t.t, and
 // with r = s - omega t the next rho and the new residual norm follow without touching r:
 //   <rhat, r> = rhat.s - omega rhat.t,   ||r||^2 = s.s - 2 omega t.s + omega^2 t.t
@@ -2333,6 +2348,24 @@ __global__ __launch_bounds__(256) void k_bicg_xrp(int64_t n, const double* __res
         const double rn = s[i] - omega * t[i];
         r[i] = rn;
         p[i] = rn + beta * (p[i] - omega * v[i]);
+    }
+}
+// ... and with the first sweep of the V-cycle the new p goes into, z = w D^-1 p (see k_bicg_s_first)
+__global__ __launch_bounds__(256) void k_bicg_xrp_first(int64_t n, const double* __restrict__ sc, const double* __restrict__ ph,
+                                                        const double* __restrict__ sh, const double* __restrict__ s,
+                                                        const double* __restrict__ t, const double* __restrict__ v,
+                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                                                        const float* __restrict__ dinv32, double omega_pc, double* __restrict__ z) {
+    const double alpha = sc[1], omega = sc[2], beta = sc[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * ph[i] + omega * sh[i];
+        const double rn = s[i] - omega * t[i];
+        r[i] = rn;
+        const double pv = rn + beta * (p[i] - omega * v[i]);
+        p[i] = pv;
+        const float4 D = *reinterpret_cast<const float4*>(dinv32 + 4 * i);
+        const double p0 = quad_bcast<0>(pv), p1 = quad_bcast<1>(pv), p2 = quad_bcast<2>(pv), p3 = quad_bcast<3>(pv);
+        z[i] = omega_pc * ((double)D.x * p0 + (double)D.y * p1 + (double)D.z * p2 + (double)D.w * p3);
     }
 }
 // sc[0..7] = (rho, alpha, omega, beta, rr, flags, 0, 0) at the start of a solve: rho = rr0 (rhat = r), beta = 0
