@@ -14,7 +14,8 @@ bcs = B.duct_bcs(m)
 sets = [("round 3", dict(amg_block_smooth=0, amg_dense_rows=0)),
         ("dense only", dict(amg_block_smooth=0)),
         ("default", dict()),
-        ("block fine too", dict(amg_block_smooth=2))]
+        ("growth check >=3 sweeps", dict(amg_growth_check=1)),
+        ("no growth check", dict(amg_growth_check=0))]
 for name, opts in sets:
     for retry in (0, 1):
         P = FlowProblem(m, bcs, reynolds=200.0, ksp_max_it=600, amg_retry_damping=retry, **opts)

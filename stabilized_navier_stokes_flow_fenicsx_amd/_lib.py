@@ -46,6 +46,7 @@ class SnsOptions(C.Structure):
         ("amg_bnu_l2", C.c_int),
         ("amg_bnu_deep", C.c_int),
         ("amg_ritz_limit", C.c_int),
+        ("amg_growth_check", C.c_int),
         ("amg_block_max_rows", C.c_int),
     ]
 

@@ -10,7 +10,7 @@
 //                CpT_i = A[i, p]^T     for every block row i != p          (copies: the update below works in place)
 //   k_gj_update  A[i, j] -= A[i, p] R_j;  A[i, p] = -A[i, p] P^-1;  A[p, j] = R_j;  A[p, p] = P^-1,
 //                and the workgroup of tile (p+1, p+1) inverts its freshly updated tile in LDS: the next step's P^-1.
-// The bulk of a step's update runs on a second stream beside the pivot chain (dense_gj_inverse).
+// (A two-stream schedule -- bulk update beside the pivot chain -- exists as an experiment: dense_gj_inverse.)
 // No pivoting across blocks (and none inside: the diagonal tiles are inverted by a block Gauss-Jordan of their own, see invert64): the level
 // operators are Galerkin projections of the stabilised form, whose symmetric part is positive definite (viscous + SUPG/LSIC
 // terms on the velocity block, the PSPG Laplacian on the pressure block; Dirichlet and empty coarse dofs are identity rows), so
@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void k_dense_matvec32(int N, int Np, const flo
 // Enqueue the blocked Gauss-Jordan inverse of the Np x Np matrix A (Np a multiple of 64, in place) on stream s.
 // work: 4 * 64 * Np doubles (R and CpT, double-buffered over the steps) + 4 * 4096 doubles (P^-1 and its transpose, likewise).
 // The pivot chain -- update of block row / column p + 1, inversion of the next pivot tile, next panel -- is the critical path
-// (40 of the 60 us of a step at N = 1900); with a second stream `side` the bulk of every step's update runs beside it:
+// (40 of the 60 us of a step at N = 1900); with a second stream `side` the bulk of every step's update runs beside it
+// (EXPERIMENT, off by default, SNS_GJ_TWO_STREAMS=1: measured slower, 3.9 against 2.4 ms at N = 1900 -- the bulk launch's 900
+// workgroups occupy every CU and the few workgroups of the chain wait for a slot instead of overtaking them):
 //   s:    panel(p) -> [U2(p-1) done] -> U1(p): tiles of row / column p + 1, then the next pivot's inverse
 //   side: [panel(p) done] -> U2(p): every other tile
 // (U1(p) needs the tiles U2(p-1) wrote; U2(p) needs R / CpT of step p and, through the panel, U1(p-1).)  side == nullptr: one stream.
