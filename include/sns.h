@@ -179,8 +179,11 @@ typedef struct {
                                level 1 at w = 0.68 against a limit of 0.45 stalls BiCGStab; oracle/experiments/r4_damping.py).
                                0: the |lambda|max rule alone */
     int    amg_growth_check; /* the growth check of the damping (six trial sweeps on the power iteration's dominant mode, w scaled by 0.9
-                               until a sweep contracts it by 10 %): 2 (default, rounds 1-3) = every level, 1 = only levels that run
-                               >= 3 sweeps per cycle, 0 = never */
+                               until a sweep contracts it by 10 %): 2 (rounds 1-3) = every level, 1 (default) = only levels that run
+                               >= 3 sweeps per cycle, 0 = never.  A level with two sweeps per cycle (the fine level) does not compound
+                               an amplified mode; backing its damping off for a few complex outliers costs smoothing everywhere else
+                               (jittered 120 x 30 x 30 duct, Re 200: 56 iterations with 1, 82 with 2, 85 with 0; no difference on
+                               BASELINE configs 3 / 4 / 4u / 5) */
     int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank (8192): there a sweep is a
                                latency-bound launch whatever it reads, and halving the sweeps halves the time; on a larger level
                                the sweep is bound by bytes and the 4 KiB of inverse per aggregate make it 1.7x a nodal-block sweep

@@ -2457,7 +2457,7 @@ void sns_default_options(sns_options* o) {
     o->amg_bnu_l2 = 3;
     o->amg_bnu_deep = 2;
     o->amg_ritz_limit = 1;
-    o->amg_growth_check = 2;
+    o->amg_growth_check = 1;
     o->amg_block_max_rows = 8192;
 }
 
