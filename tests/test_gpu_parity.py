@@ -510,6 +510,50 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
         assert outs[0][5] == 2                                                # fine + the replicated, directly solved level 1
 
 
+def test_asymmetric_halo_plan_is_refused_on_every_rank(gpu):
+    """both ends of every halo link must post matching counts, zero included -- an asymmetric plan deadlocks an
+    RCCL send / recv group.  sns_attach_comm / sns_attach_team compare the plans collectively (one all-gather of the per-peer
+    counts) and EVERY rank gets the same error instead of some of them hanging: here rank 1 of 3 drops the last node it should
+    send to rank 0, and a second run has rank 2 forget a neighbour altogether."""
+    import copy
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M, partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd._lib import SnsError
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    m = M.duct_mesh((18, 4, 4), 3.0)
+    mask, g = B.duct_bcs(m).flatten()
+    owner = PT.rcb_partition(m.points, 3)
+    for variant in ("short send list", "missing neighbour"):
+        team = Team(3)
+        errors = [None] * 3
+
+        def work(rank, team):
+            part = copy.deepcopy(PT.build_local_part(m, mask, g, owner, rank, 3))
+            nb = [int(x) for x in part.neighbors]
+            if variant == "short send list" and rank == 1:
+                k = nb.index(0)                                  # one node less towards rank 0
+                keep = np.ones(len(part.send_idx), bool)
+                keep[part.send_ptr[k + 1] - 1] = False
+                part.send_idx = part.send_idx[keep]
+                part.send_ptr = part.send_ptr.copy()
+                part.send_ptr[k + 1:] -= 1
+            if variant == "missing neighbour" and rank == 2:
+                k = len(nb) - 1                                  # rank 2 forgets its last neighbour
+                part.send_idx = part.send_idx[:part.send_ptr[k]]
+                part.recv_idx = part.recv_idx[:part.recv_ptr[k]]
+                part.send_ptr, part.recv_ptr = part.send_ptr[:k + 1], part.recv_ptr[:k + 1]
+                part.neighbors = part.neighbors[:k]
+            try:
+                P = gpu(part.mesh, (part.bc_mask, part.bc_val), reynolds=5.0, part=part, group=team)
+                P.close()
+            except SnsError as e:
+                errors[rank] = str(e)
+
+        team.run(work)
+        team.close()
+        assert all(e is not None and "halo plan of level 0" in e for e in errors), (variant, errors)
+        assert len(set(errors)) == 1, errors                     # the same verdict everywhere
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_two_stream_halo_overlap_matches_exchange_then_full_pass(gpu, nranks, monkeypatch):
     """exchange_and_spmv's production branch (interior rows on the side stream while the halo is in flight, boundary
