@@ -485,7 +485,9 @@ def test_n_rank_solver_through_team_transport(gpu, nranks, kind, monkeypatch):
         if kind == "slab":
             P.time_kernels(False)
             kt = P.kernel_times()
-            for key in ("jacobi", "b_minus_ax", "ax", "ax_dot"):
+            # (no full fine-level Jacobi sweep is left in a default cycle since round 4: the first sweep rides on the Krylov
+            # vector kernels, the post-sweep on M = A P, and the damping's growth check skips two-sweep levels)
+            for key in ("b_minus_ax", "ax", "ax_dot", "post_m"):
                 assert kt[key][1] > 0 and kt[key][0] > 0.0, (key, kt)
         out = (part, U.cpu().numpy(), r, w.cpu().numpy(), n, P.timings().amg_levels, c, sizes)
         P.close()

@@ -43,3 +43,13 @@ def test_c_krylov_reaches_lu_solution(method, pc):
         x, its, reason, rn = cport.solve(m.num_nodes, rp, ci, vals, -F0, method=method, pc=pc, nblocks=nblocks, rtol=1e-10)
         assert reason > 0, (its, reason, rn)
         assert rel(x, Uo) < 1e-6
+        info = cport.last_solve_info()
+        # what bench.py's cpu_baseline reports beside the reason: the value the stopping test ran on (tfqmr: PETSc's quasi-residual
+        # bound tau*sqrt(m+1), which runs ahead of the residual), whether it met the tolerance, and the TRUE residual
+        assert info["petsc_criterion_met"] and info["tested"] <= 1e-10 * info["bnorm"] * (1 + 1e-12)
+        assert abs(info["true_residual"] - rn) <= 1e-12 * info["bnorm"] + 1e-6 * rn
+        assert info["true_residual"] <= 10 * 1e-10 * info["bnorm"]
+    # an iteration bound that is too small: not converged by any criterion, and the info says so
+    x, its, reason, rn = cport.solve(m.num_nodes, rp, ci, vals, -F0, method=method, pc=pc, nblocks=1, rtol=1e-10, maxit=2)
+    info = cport.last_solve_info()
+    assert reason == -3 and its == 2 and not info["petsc_criterion_met"] and info["true_residual"] > 1e-10 * info["bnorm"]
