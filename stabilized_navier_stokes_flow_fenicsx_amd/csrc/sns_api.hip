@@ -596,12 +596,12 @@ void launch_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double*
         const int32_t ns = 8 * L.n_blk;
         const unsigned grid = (unsigned)((ns + 63) / 64);
         if (grid == 0) return;
-        if (lp_format(h, L) == 2)
+        if (L.binv_fmt == 2)
             hipLaunchKernelGGL((k_bsweep<2>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals16, L.scale16, (const float4*)L.binv32, x, y, b, omega);
+                               (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega);
         else
             hipLaunchKernelGGL((k_bsweep<1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals32, (const float*)nullptr, (const float4*)L.binv32, x, y, b, omega);
+                               (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega);
         return;
     }
     launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x, y, b, omega);
@@ -612,8 +612,12 @@ void launch_first_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const d
     const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
     if (block_active(h, l) && L.binv32) {
         const int32_t ns = 8 * L.n_blk;
-        hipLaunchKernelGGL(k_bfirst, dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
-                           (const float4*)L.binv32, b, omega, z);
+        if (L.binv_fmt == 2)
+            hipLaunchKernelGGL((k_bfirst<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
+                               (const void*)L.binv32, b, omega, z);
+        else
+            hipLaunchKernelGGL((k_bfirst<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
+                               (const void*)L.binv32, b, omega, z);
     } else if (lp_format(h, L) != 0 && L.dinv32) {
         hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, omega, z);
     } else {
@@ -1389,10 +1393,23 @@ int pc_setup(sns_ctx* h) {
             hipLaunchKernelGGL(k_dinv, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rows, L.diag, L.vals, L.dinv);
         if (block_active(h, l)) {
             // the aggregates' inverse diagonal blocks, from the fp64 operator (what the nodal D^-1 is to the point smoother)
-            if (!L.binv32) SNS_TRY(dev_alloc(&L.binv32, (size_t)1024 * std::max(1, L.n_blk)));
-            if (L.n_blk > 0)
-                hipLaunchKernelGGL(k_binv, dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.blk_rows, L.blk_of,
-                                   L.rowptr, L.colind, L.vals, (float4*)L.binv32, h->d_sing);
+            // ... in the format of the level's matrix copy (fp32, or fp16 with row scales: half the bytes of a block sweep's extra stream)
+            const int bf = h->opt.amg_f32_matrix == 2 ? 2 : 1;
+            if (L.binv32 && L.binv_fmt != bf) { (void)hipFree(L.binv32); L.binv32 = nullptr; }
+            if (!L.binv32) {
+                uint8_t* pb = nullptr;
+                SNS_TRY(dev_alloc(&pb, binv_bytes_per_block(bf) * (size_t)std::max(1, L.n_blk)));
+                L.binv32 = pb;
+                L.binv_fmt = bf;
+            }
+            if (L.n_blk > 0) {
+                if (bf == 2)
+                    hipLaunchKernelGGL((k_binv<2>), dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.blk_rows,
+                                       L.blk_of, L.rowptr, L.colind, L.vals, L.binv32, h->d_sing);
+                else
+                    hipLaunchKernelGGL((k_binv<1>), dim3((unsigned)((L.n_blk + 7) / 8)), dim3(256), 0, h->stream, L.n_blk, L.blk_rows,
+                                       L.blk_of, L.rowptr, L.colind, L.vals, L.binv32, h->d_sing);
+            }
             any_block = true;
         }
         L.omega = h->opt.amg_omega * h->damping_backoff;
@@ -1820,8 +1837,12 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         }
         if (fuse && block_active(h, l + 1)) {
             const int32_t ns = 8 * C.n_blk;
-            hipLaunchKernelGGL(k_restrict_blk, dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows, L.m_ptr,
-                               L.m_idx, L.free_mask, L.r, C.b, (const float4*)C.binv32, C.omega, zc);
+            if (C.binv_fmt == 2)
+                hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, (const void*)C.binv32, C.omega, zc);
+            else
+                hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, (const void*)C.binv32, C.omega, zc);
         } else {
             hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
                                C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, dc, C.omega, zc);
@@ -1855,11 +1876,11 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
                 const unsigned gb = (unsigned)((ns + 63) / 64);
                 if (fmt_l == 2)
                     hipLaunchKernelGGL((k_bpost<2>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
-                                       (const void*)L.ap_vals16, L.ap_scale16, (const float4*)L.binv32, xc, cur, L.r, om, L.agg,
+                                       (const void*)L.ap_vals16, L.ap_scale16, (const void*)L.binv32, xc, cur, L.r, om, L.agg,
                                        L.free_mask, oth);
                 else
                     hipLaunchKernelGGL((k_bpost<1>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
-                                       (const void*)L.ap_vals32, (const float*)nullptr, (const float4*)L.binv32, xc, cur, L.r, om,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, (const void*)L.binv32, xc, cur, L.r, om,
                                        L.agg, L.free_mask, oth);
             } else if (fmt_l == 2) {
                 if (fine)
@@ -2454,11 +2475,11 @@ void sns_default_options(sns_options* o) {
     o->amg_dense_rows = 512;
     o->amg_block_smooth = 1;
     o->amg_bnu_l1 = 3;
-    o->amg_bnu_l2 = 3;
+    o->amg_bnu_l2 = 4;
     o->amg_bnu_deep = 2;
     o->amg_ritz_limit = 1;
     o->amg_growth_check = 1;
-    o->amg_block_max_rows = 8192;
+    o->amg_block_max_rows = 0;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }

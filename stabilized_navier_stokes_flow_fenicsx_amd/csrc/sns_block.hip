@@ -107,19 +107,58 @@ __device__ __forceinline__ double lp_row_times_x(int32_t s, int32_t e, const int
     return acc0 + acc1;
 }
 
+// Row j of an aggregate's inverse block B_G^-1, in the format of the level's matrix copy: BF 1 = fp32 (4 KiB per aggregate, stored
+// [k/4][j] as float4), BF 2 = fp16 with one fp32 scale per row (row-max normalisation like the fp16 matrix copy: 2 KiB + 128 B per
+// aggregate, stored [k/8][j] as 8 halfs = 16 B, the 32 scales behind them).  Either way a half-wave reads 512 contiguous bytes per
+// load instruction, requested before the row loop.
+template <int BF> struct BinvRow;
+template <> struct BinvRow<1> {
+    float4 v[8];
+    __device__ __forceinline__ void load(const void* __restrict__ binv, int64_t G, int j, bool in) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(binv) + G * 256 + j;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) v[k4] = in ? p[k4 * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ double dot(const double* __restrict__ sr) const {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const double2 r01 = *reinterpret_cast<const double2*>(sr + 4 * k4), r23 = *reinterpret_cast<const double2*>(sr + 4 * k4 + 2);
+            a0 += (double)v[k4].x * r01.x + (double)v[k4].z * r23.x;
+            a1 += (double)v[k4].y * r01.y + (double)v[k4].w * r23.y;
+        }
+        return a0 + a1;
+    }
+};
+template <> struct BinvRow<2> {
+    uint4 h[4];
+    float sc;
+    __device__ __forceinline__ void load(const void* __restrict__ binv, int64_t G, int j, bool in) {
+        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(binv) + G * 136 + j;          // 128 uint4 of halfs + 8 of scales
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) h[k8] = in ? p[k8 * 32] : make_uint4(0u, 0u, 0u, 0u);
+        sc = in ? reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(binv) + G * 136 + 128)[j] : 0.f;
+    }
+    __device__ __forceinline__ double dot(const double* __restrict__ sr) const {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const f16x8_t q = *reinterpret_cast<const f16x8_t*>(&h[k8]);
+            const double2 r01 = *reinterpret_cast<const double2*>(sr + 8 * k8), r23 = *reinterpret_cast<const double2*>(sr + 8 * k8 + 2);
+            const double2 r45 = *reinterpret_cast<const double2*>(sr + 8 * k8 + 4), r67 = *reinterpret_cast<const double2*>(sr + 8 * k8 + 6);
+            a0 += (double)(float)q[0] * r01.x + (double)(float)q[2] * r23.x + (double)(float)q[4] * r45.x + (double)(float)q[6] * r67.x;
+            a1 += (double)(float)q[1] * r01.y + (double)(float)q[3] * r23.y + (double)(float)q[5] * r45.y + (double)(float)q[7] * r67.y;
+        }
+        return (double)sc * (a0 + a1);
+    }
+};
 // (B_G^-1 res)[j] for lane j of the half-wave that holds aggregate G's residual (one entry per lane); sr = this half-wave's 32
 // doubles of LDS.  Every thread of the workgroup must call it (barrier inside).
-__device__ __forceinline__ double block_apply(const float4 (&Bv)[8], double res, double* __restrict__ sr, int j) {
+template <int BF>
+__device__ __forceinline__ double block_apply(const BinvRow<BF>& B, double res, double* __restrict__ sr, int j) {
     sr[j] = res;
     __syncthreads();
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-        const double2 r01 = *reinterpret_cast<const double2*>(sr + 4 * k4), r23 = *reinterpret_cast<const double2*>(sr + 4 * k4 + 2);
-        a0 += (double)Bv[k4].x * r01.x + (double)Bv[k4].z * r23.x;
-        a1 += (double)Bv[k4].y * r01.y + (double)Bv[k4].w * r23.y;
-    }
-    return a0 + a1;
+    return B.dot(sr);
 }
 
 }  // namespace
@@ -129,7 +168,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* __restrict__ blk_rows,
                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                 const void* __restrict__ vals_v, const float* __restrict__ scale,
-                                                const float4* __restrict__ binv, const double* __restrict__ x,
+                                                const void* __restrict__ binv, const double* __restrict__ x,
                                                 double* __restrict__ y, const double* __restrict__ bvec, double omega) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
@@ -137,10 +176,8 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
-    float4 Bv[8];
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4)
-        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    BinvRow<FMT> Bv;
+    Bv.load(binv, slot >> 3, j, in);
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
     double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
     if (live) {
@@ -153,9 +190,9 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
     if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
 }
 template __global__ void k_bsweep<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                     const float4*, const double*, double*, const double*, double);
+                                     const void*, const double*, double*, const double*, double);
 template __global__ void k_bsweep<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                     const float4*, const double*, double*, const double*, double);
+                                     const void*, const double*, double*, const double*, double);
 
 // coarse-grid correction + first post-smoothing sweep over M = A P with the aggregate blocks (k_post_lp's algebra):
 //     y = (x1 + P xc) + w B^-1 (r1 - M xc)
@@ -163,7 +200,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* __restrict__ blk_rows,
                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                const void* __restrict__ vals_v, const float* __restrict__ scale,
-                                               const float4* __restrict__ binv, const double* __restrict__ xc,
+                                               const void* __restrict__ binv, const double* __restrict__ xc,
                                                const double* __restrict__ x_pre, const double* __restrict__ res1, double omega,
                                                const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
                                                double* __restrict__ y) {
@@ -173,10 +210,8 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
-    float4 Bv[8];
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4)
-        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    BinvRow<FMT> Bv;
+    Bv.load(binv, slot >> 3, j, in);
     const int32_t s = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
     double pre_b = 0.0, pre_x = 0.0, sc = 1.0;
     if (live) {
@@ -191,15 +226,16 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
     if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
 }
 template __global__ void k_bpost<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                    const float4*, const double*, const double*, const double*, double, const int32_t*,
+                                    const void*, const double*, const double*, const double*, double, const int32_t*,
                                     const uint8_t*, double*);
 template __global__ void k_bpost<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                    const float4*, const double*, const double*, const double*, double, const int32_t*,
+                                    const void*, const double*, const double*, const double*, double, const int32_t*,
                                     const uint8_t*, double*);
 
 // z = w B^-1 b: the first sweep of a cycle (zero initial guess); with w = 1 the B^-1 of the spectral estimate
+template <int FMT>
 __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* __restrict__ blk_rows,
-                                                const float4* __restrict__ binv, const double* __restrict__ bvec, double omega,
+                                                const void* __restrict__ binv, const double* __restrict__ bvec, double omega,
                                                 double* __restrict__ z) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
@@ -207,22 +243,23 @@ __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* 
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
-    float4 Bv[8];
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4)
-        Bv[k4] = in ? binv[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    BinvRow<FMT> Bv;
+    Bv.load(binv, slot >> 3, j, in);
     const double zz = block_apply(Bv, live ? bvec[4 * (int64_t)row + r] : 0.0, sres + 32 * (tid >> 5), j);
     if (live) z[4 * (int64_t)row + r] = omega * zz;
 }
+template __global__ void k_bfirst<1>(int32_t, const int32_t*, const void*, const double*, double, double*);
+template __global__ void k_bfirst<2>(int32_t, const int32_t*, const void*, const double*, double, double*);
 
 // Restriction to a level that is smoothed with aggregate blocks, fused with that level's first sweep from the zero guess:
 //     bc[I] = sum_{i in I} free_i r[i]   (k_restrict's gather, same member order => same bits),     z = w_c B_c^-1 bc.
 // The coarse nodes are walked in the order of THEIR aggregates (blk_rows_c of the coarse level), so that the 32 lanes of a
 // half-wave hold one coarse aggregate's right-hand side when it is complete -- one dependent launch less per level and cycle.
+template <int FMT>
 __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int32_t* __restrict__ blk_rows_c,
                                                       const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
                                                       const uint8_t* __restrict__ free_mask, const double* __restrict__ r,
-                                                      double* __restrict__ bc, const float4* __restrict__ binv_c, double omega_c,
+                                                      double* __restrict__ bc, const void* __restrict__ binv_c, double omega_c,
                                                       double* __restrict__ z_c) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
@@ -230,10 +267,8 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
     const bool in = slot < n_slots;
     const int32_t I = in ? blk_rows_c[slot] : -1;
     const bool live = I >= 0;
-    float4 Bv[8];
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4)
-        Bv[k4] = in ? binv_c[((int64_t)(slot >> 3) * 8 + k4) * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    BinvRow<FMT> Bv;
+    Bv.load(binv_c, slot >> 3, j, in);
     double s = 0.0;
     if (live) {
         const int32_t k0 = m_ptr[I], k1 = m_ptr[I + 1];
@@ -255,14 +290,19 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
     const double zz = block_apply(Bv, live ? s : 0.0, sres + 32 * (tid >> 5), j);
     if (live) z_c[4 * (int64_t)I + c] = omega_c * zz;
 }
+template __global__ void k_restrict_blk<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, const double*,
+                                           double*, const void*, double, double*);
+template __global__ void k_restrict_blk<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, const double*,
+                                           double*, const void*, double, double*);
 
 // B_G^-1 of every smoother block from the level's fp64 operator: 8 blocks per workgroup, 32 lanes each (lane j = column j of the
 // 32 x 32 block in LDS).  Member slots a block does not fill keep identity rows / columns.  (Blocks = the aggregates; the rare
 // aggregate of more than 8 nodes -- a leftover node joins a full neighbour -- is split into chunks of 8 in member order: the
 // smoother's partition need not be the coarsening's.  blk_of[node] = the block of a node, -1 for ghost nodes.)
+template <int FMT>
 __global__ __launch_bounds__(256) void k_binv(int32_t nblk, const int32_t* __restrict__ blk_rows, const int32_t* __restrict__ blk_of,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
-                                              const double* __restrict__ vals, float4* __restrict__ binv,
+                                              const double* __restrict__ vals, void* __restrict__ binv_v,
                                               int* __restrict__ singular) {
     __shared__ double lds[8 * 32 * 33];
     const int tid = threadIdx.x, ha = tid >> 5, j = tid & 31;
@@ -307,11 +347,30 @@ __global__ __launch_bounds__(256) void k_binv(int32_t nblk, const int32_t* __res
         __syncthreads();
     }
     if (G < nblk) {
+        if (FMT == 1) {
+            float4* __restrict__ binv = reinterpret_cast<float4*>(binv_v);
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4)
-            binv[((int64_t)G * 8 + k4) * 32 + j] = make_float4((float)M[j * 33 + 4 * k4], (float)M[j * 33 + 4 * k4 + 1],
-                                                               (float)M[j * 33 + 4 * k4 + 2], (float)M[j * 33 + 4 * k4 + 3]);
+            for (int k4 = 0; k4 < 8; ++k4)
+                binv[((int64_t)G * 8 + k4) * 32 + j] = make_float4((float)M[j * 33 + 4 * k4], (float)M[j * 33 + 4 * k4 + 1],
+                                                                   (float)M[j * 33 + 4 * k4 + 2], (float)M[j * 33 + 4 * k4 + 3]);
+        } else {
+            // fp16 with the row's largest |entry| as scale (nothing overflows or underflows the half range)
+            double mx = 0.0;
+            for (int k = 0; k < 32; ++k) mx = fmax(mx, fabs(M[j * 33 + k]));
+            const double inv = mx > 0.0 ? 1.0 / mx : 0.0;
+            uint4* __restrict__ base = reinterpret_cast<uint4*>(binv_v) + (int64_t)G * 136;
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {
+                f16x8_t q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = (_Float16)(float)(M[j * 33 + 8 * k8 + e] * inv);
+                base[k8 * 32 + j] = *reinterpret_cast<const uint4*>(&q);
+            }
+            reinterpret_cast<float*>(base + 128)[j] = (float)mx;
+        }
     }
 }
+template __global__ void k_binv<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*, void*, int*);
+template __global__ void k_binv<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*, void*, int*);
 
 }  // namespace sns

@@ -87,7 +87,8 @@ struct Level {
     int32_t* blk_rows = nullptr;
     int32_t* blk_of = nullptr;           // node -> its smoother block (-1: ghost node)
     int32_t n_blk = 0;                   // smoother blocks (= nc, plus one per aggregate of more than 8 nodes)
-    float* binv32 = nullptr;
+    void* binv32 = nullptr;              // (fp32 blocks, or fp16 + row scales: the format of the level's matrix copy, binv_fmt)
+    int binv_fmt = 0;
     // work vectors (4*n doubles)
     double *x = nullptr, *b = nullptr, *r = nullptr;
     double* xg = nullptr;                // distributed runs: copy of the iterate whose ghost tail is exchanged

@@ -120,19 +120,24 @@ __global__ void k_dense_to_f32(int64_t n, const double* A, float* X);
 __global__ void k_dense_matvec32(int N, int Np, const float* X, const double* b, double* y);
 void dense_gj_inverse(hipStream_t s, hipStream_t side, int Np, double* A, double* work, int* singular);
 inline size_t dense_gj_work_doubles(int Np) { return (size_t)4 * 64 * Np + 4 * 4096; }
-// csrc/sns_block.hip: aggregate-block Jacobi smoother of the coarse levels
+// csrc/sns_block.hip: aggregate-block Jacobi smoother of the coarse levels (FMT = format of the level's matrix copy AND of the
+// aggregates' inverse blocks: 1 fp32, 2 fp16 with row scales)
 template <int FMT>
 __global__ void k_bsweep(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
-                         const float* scale, const float4* binv, const double* x, double* y, const double* bvec, double omega);
+                         const float* scale, const void* binv, const double* x, double* y, const double* bvec, double omega);
 template <int FMT>
 __global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
-                        const float* scale, const float4* binv, const double* xc, const double* x_pre, const double* res1,
+                        const float* scale, const void* binv, const double* xc, const double* x_pre, const double* res1,
                         double omega, const int32_t* agg, const uint8_t* free_mask, double* y);
-__global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const float4* binv, const double* bvec, double omega, double* z);
+template <int FMT>
+__global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const void* binv, const double* bvec, double omega, double* z);
+template <int FMT>
 __global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
-                               const uint8_t* free_mask, const double* r, double* bc, const float4* binv_c, double omega_c, double* z_c);
+                               const uint8_t* free_mask, const double* r, double* bc, const void* binv_c, double omega_c, double* z_c);
+template <int FMT>
 __global__ void k_binv(int32_t nblk, const int32_t* blk_rows, const int32_t* blk_of, const int32_t* rowptr, const int32_t* colind,
-                       const double* vals, float4* binv, int* singular);
+                       const double* vals, void* binv, int* singular);
+inline size_t binv_bytes_per_block(int fmt) { return fmt == 2 ? (size_t)136 * 16 : (size_t)4096; }
 __global__ void k_pack(int32_t m, const int32_t* idx, const double* x, double* buf);
 __global__ void k_unpack(int32_t m, const int32_t* idx, const double* buf, double* x);
 __global__ void k_fill_pattern(int64_t n, double* x);
