@@ -163,13 +163,14 @@ typedef struct {
     int    amg_block_smooth; /* (round 4) 1 (default): the smoothed levels >= 1 use AGGREGATE-block Jacobi -- the dense block of the
                                <= 8 nodes (32 dofs) that form one node of the next level, inverted at every numeric setup, in place
                                of the 4 x 4 nodal block: x <- x + w B^-1 (b - A x), one launch per sweep like before and worth about
-                               two point-block sweeps, so the levels run the shorter schedule below (csrc/sns_block.hip).  2: the
-                               fine level as well (4 KiB of inverse per aggregate).  0: nodal blocks everywhere (rounds 1-3).
+                               two point-block sweeps, so the levels run the shorter schedule below (csrc/sns_block.hip).  The inverse
+                               blocks are held in the format of the level's matrix copy (fp16 + one fp32 scale per row by default,
+                               2 KiB + 128 B per aggregate; fp32 with amg_f32_matrix = 1).  2: the fine level as well.  0: nodal blocks everywhere (rounds 1-3).
                                Needs amg_f32_matrix != 0 and amg_agg_size <= 8; levels where it does not apply keep the nodal
                                blocks and their sweep counts.  Fixed when the hierarchy is built */
     int    amg_bnu_l1;      /* sweeps after the coarse-grid correction on level 1 under amg_block_smooth (3; one sweep before it);
                                a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*) */
-    int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (3) */
+    int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (4) */
     int    amg_bnu_deep;    /* ... and on levels >= 3 (2: the nodal blocks' count, with the stronger smoother).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
     int    amg_ritz_limit;  /* 1 (default): on every level that runs 3 or more sweeps per cycle the damping is also capped by the
                                STABILITY limit of the dominant Ritz values of S A (S = the smoother's block inverse) from 8 Arnoldi
@@ -184,11 +185,10 @@ typedef struct {
                                an amplified mode; backing its damping off for a few complex outliers costs smoothing everywhere else
                                (jittered 120 x 30 x 30 duct, Re 200: 56 iterations with 1, 82 with 2, 85 with 0; no difference on
                                BASELINE configs 3 / 4 / 4u / 5) */
-    int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank (8192): there a sweep is a
-                               latency-bound launch whatever it reads, and halving the sweeps halves the time; on a larger level
-                               the sweep is bound by bytes and the 4 KiB of inverse per aggregate make it 1.7x a nodal-block sweep
-                               (27 k rows: 10 against 5.5 us; 218 k rows: +50 % bytes), so half the sweeps buy nothing and cost
-                               iterations (10 M-tet duct: +4 ... 9 %).  0 = no limit */
+    int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank; 0 (default) = no limit.  (While the
+                               inverse blocks were fp32 -- 4 KiB per aggregate -- a block sweep cost 1.5x a nodal sweep on a large
+                               level and the limit was 8192; in the format of the level's fp16 matrix copy, 2 KiB + row scales, it
+                               costs 1.2x and every coarse level gains: 10 M-tet duct 137.5 -> 127-130 ms per Newton iteration) */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
