@@ -40,7 +40,7 @@ typedef struct sns_ctx* sns_handle;
 #define SNS_E_HIP        -2   /* HIP runtime error (see sns_last_error)   */
 #define SNS_E_STATE      -3   /* call order (e.g. solve before assemble)  */
 #define SNS_E_MESH       -4   /* degenerate / inverted input mesh         */
-#define SNS_E_COMM       -5   /* RCCL error                               */
+#define SNS_E_COMM       -5   /* RCCL / peer-transport error              */
 
 /* weak forms */
 #define SNS_FORM_STOKES   0   /* setup_stokes_weak_form      :160-172 */
@@ -198,7 +198,7 @@ const char* sns_version(void);
  * and the fixed-size out-arrays of the getters below have grown (sns_get_counters / sns_get_kernel_times: 4 -> 8 entries in
  * round 3), so a binding built against an older header would pass short buffers: bindings compare both numbers with the
  * header they were written against before making any other call (the ctypes mirror does, _lib.py) and refuse on a mismatch. */
-#define SNS_ABI_VERSION 4
+#define SNS_ABI_VERSION 5
 int sns_abi_version(void);
 int64_t sns_options_size(void);
 
@@ -261,6 +261,25 @@ int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
 
+/* Peer-window communicator (PRODUCT TRANSPORT for the ranks of ONE node, round 4): no library in the data path.  Every rank
+ * owns a window of fine-grained device memory that the other ranks map through HIP IPC; halo exchange, all-reduce and
+ * all-gather are small kernels that store into the peers' windows over xGMI and raise sequence flags there (csrc/sns_comm.h).
+ * It replaces the same PETSc/MPI traffic as sns_attach_comm (VecGhostUpdate inside MatMult, the KSP's MPI_Allreduce) where the
+ * RCCL launch floor (~50 us per send/recv group, ~10 us per all-reduce on this image) dominates: the strong split.
+ *   sns_peer_create  : allocate this rank's window (window_bytes, 0 = 64 MiB) on `device`; ipc_handle_out = 64 bytes for the peers
+ *   sns_peer_connect : ipc_handles = nranks x 64 bytes in rank order (all-gathered by the caller, e.g. torch.distributed);
+ *                      call on every rank, then synchronise the ranks once before the first attach
+ *   sns_attach_peer  : as sns_attach_comm (same plan arguments; rank / nranks are the communicator's); collective
+ *   sns_peer_destroy : after every handle attached to it is destroyed AND the ranks have synchronised
+ * At most 16 ranks.  Every device-side wait is bounded (SNS_PEER_TIMEOUT_MS, default 20000): a late or dead peer turns into
+ * SNS_E_COMM at the next host synchronisation instead of a hang.                                                          */
+int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]);
+int sns_peer_connect(void* peer, const char* ipc_handles);
+int sns_peer_destroy(void* peer);
+int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
+                    const int32_t* send_ptr, const int32_t* send_idx,
+                    const int32_t* recv_ptr, const int32_t* recv_idx);
+
 /* ---- hot path --------------------------------------------------------------*/
 /* NonlinearPDE_SNESProblem.F (:51-67): F(w) incl. lifting and F_B = w_B - g.
  * form = SNS_FORM_NS, or SNS_FORM_STOKES for the linear residual A w - b.     */
@@ -320,7 +339,7 @@ int sns_get_timings(sns_handle h, sns_timings* t);
  * out[6] = reason of the first attempt of the last solve if it was retried (else 0), out[7] = blocks of the fine level's
  * M = A P (fused post-smoothing sweep; 0 until the hierarchy exists) */
 int sns_get_counters(sns_handle h, int64_t out[8]);
-/* communicator of the handle: out[0] = transport (0 none, 1 RCCL, 2 in-process team), out[1] = this rank,
+/* communicator of the handle: out[0] = transport (0 none, 1 RCCL, 2 in-process team, 3 peer windows), out[1] = this rank,
  * out[2] = ranks the handle was attached with, out[3] = ranks RCCL itself reports (ncclCommCount; 0 without RCCL):
  * bench.py prints it so that "did RCCL see N ranks" can be read off the result line */
 int sns_comm_info(sns_handle h, int32_t out[4]);

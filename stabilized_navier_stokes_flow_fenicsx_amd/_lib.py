@@ -58,7 +58,7 @@ class SnsTimings(C.Structure):
 
 
 # constants of sns.h
-ABI_VERSION = 4                          # SNS_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 5                          # SNS_ABI_VERSION of the header this mirror was written against
 FORM_STOKES, FORM_NS = 0, 1
 KSP_BICGSTAB, KSP_FGMRES, KSP_TFQMR = 0, 1, 2
 PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2
@@ -88,6 +88,10 @@ _SIGNATURES = [
     ("sns_team_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("sns_team_destroy", C.c_int, [_P]),
     ("sns_attach_team", C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
+    ("sns_peer_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(_P), C.c_char_p]),
+    ("sns_peer_connect", C.c_int, [_P, C.c_char_p]),
+    ("sns_peer_destroy", C.c_int, [_P]),
+    ("sns_attach_peer", C.c_int, [_H, _P, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
     ("sns_residual", C.c_int, [_H, C.c_int, _P, _P]),
     ("sns_jacobian", C.c_int, [_H, C.c_int, _P, _P]),
     ("sns_spmv", C.c_int, [_H, _P, _P]),

@@ -265,6 +265,7 @@ int fetch(sns_ctx* h, const double* src_dev, int count, double* out) {
     HIP_TRY(hipMemcpyAsync(h->h_scal, src_dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     ++h->ctr_host_syncs;
+    SNS_TRY(peer_check(h->comm.get()));          // (peer transport: a collective behind this result may have given up waiting)
     std::memcpy(out, h->h_scal, count * sizeof(double));
     return SNS_OK;
 }
@@ -412,7 +413,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
     s2.mode = 2;
     s2.partial_off = gs;
     if (MODE == SPMV_AX_DOT) h->bnd_dot_blocks = (h->n_bnd + 31) / 32;
-    if (c->nccl || h->team_overlap) {
+    if (c->nccl || c->peer || h->team_overlap) {
         // (team transport with SNS_TEAM_OVERLAP=1: the same two-stream choreography -- interior pass on the side
         // stream, event joins, per-launch timing events on that stream -- over the emulated exchange, so that the
         // stream dependencies of the production path are exercised on a 1-GPU box)
@@ -471,6 +472,7 @@ int global_sum(sns_ctx* h, double* v, int count) {
     HIP_TRY(hipMemcpy(h->d_scal + 64, v, count * sizeof(double), hipMemcpyHostToDevice));
     SNS_TRY(comm_allreduce_sum(c, h->d_scal + 64, count, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    SNS_TRY(peer_check(c));
     HIP_TRY(hipMemcpy(v, h->d_scal + 64, count * sizeof(double), hipMemcpyDeviceToHost));
     return SNS_OK;
 }
@@ -485,6 +487,7 @@ int host_allgather(sns_ctx* h, const std::vector<double>& mine, std::vector<doub
     HIP_TRY(hipMemcpy(ds, mine.data(), len * sizeof(double), hipMemcpyHostToDevice));
     SNS_TRY(comm_allgather(c, ds, dr, (int)len, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    SNS_TRY(peer_check(c));
     all.resize(len * c->nranks);
     HIP_TRY(hipMemcpy(all.data(), dr, all.size() * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(ds);
@@ -527,6 +530,20 @@ int check_plan_symmetry(sns_ctx* h, const Plan& p, int level) {
         }
     }
     return SNS_OK;
+}
+
+// peer transport: wire an uploaded plan to the neighbours' windows (collective, like check_plan_symmetry before it)
+int connect_plan(sns_ctx* h, Plan& p) {
+    Comm* c = h->comm.get();
+    if (!c || !c->peer) return SNS_OK;
+    PlanOffers t;
+    const int rc = peer_plan_offer(c, p, t);
+    if (rc != SNS_OK) t.mine.assign((size_t)3 * c->nranks, -2.0);      // (still take part in the all-gather: the peers must not hang)
+    SNS_TRY(host_allgather(h, t.mine, t.all));
+    if (rc != SNS_OK) return rc;
+    for (double v : t.all)
+        if (v == -2.0) { set_error("peer transport: a rank could not place the plan in its window"); return SNS_E_COMM; }
+    return peer_plan_connect(c, p, t);
 }
 
 int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg) {
@@ -914,6 +931,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
             HIP_TRY(hipMemset(C.xg, 0, 4 * (size_t)C.n * sizeof(double)));
             SNS_TRY(check_plan_symmetry(h, cplan, l + 1));
             SNS_TRY(plan_upload(cplan));
+            SNS_TRY(connect_plan(h, cplan));
             c->plans.push_back(std::move(cplan));
         }
         h->ghost_own.push_back(std::move(g_own));
@@ -2102,6 +2120,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             }
             HIP_TRY(hipEventSynchronize(h->ev_it));
             ++h->ctr_host_syncs;
+            SNS_TRY(peer_check(h->comm.get()));
             const double rr = hpin[0];
             const int flags = (int)hpin[1];
             rn = std::sqrt(rr);
@@ -2746,7 +2765,7 @@ int sns_comm_unique_id(char id_out[128]) {
     return SNS_OK;
 }
 
-static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Team* team, int32_t n_owned, int n_nbr,
+static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Team* team, Peer* peer, int32_t n_owned, int n_nbr,
                          const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx,
                          const int32_t* recv_ptr, const int32_t* recv_idx) {
     if (!h || nranks < 1 || rank < 0 || rank >= nranks || n_owned < 0 || n_owned > h->n || n_nbr < 0 ||
@@ -2764,6 +2783,7 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     c.rank = rank;
     c.nranks = nranks;
     c.team = team;
+    c.peer = peer;
     if (uid) {
         ncclUniqueId id;
         std::memcpy(&id, uid, 128);
@@ -2814,13 +2834,14 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     // first collective of the communicator: both ends of every link agree on its counts (the coarse levels' plans are
     // checked the same way when the hierarchy derives them)
     SNS_TRY(check_plan_symmetry(h, c.plans[0], 0));
+    SNS_TRY(connect_plan(h, c.plans[0]));
     return SNS_OK;
 }
 
 int sns_attach_comm(sns_handle h, int rank, int nranks, const char uid[128], int32_t n_owned, int n_nbr,
                     const int32_t* nbr, const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
                     const int32_t* recv_idx) {
-    return attach_common(h, rank, nranks, uid, nullptr, n_owned, n_nbr, nbr, send_ptr, send_idx, recv_ptr, recv_idx);
+    return attach_common(h, rank, nranks, uid, nullptr, nullptr, n_owned, n_nbr, nbr, send_ptr, send_idx, recv_ptr, recv_idx);
 }
 
 int sns_team_create(int nranks, void** team_out) {
@@ -2836,8 +2857,25 @@ int sns_attach_team(sns_handle h, void* team, int rank, int nranks, int32_t n_ow
                     const int32_t* send_ptr, const int32_t* send_idx, const int32_t* recv_ptr,
                     const int32_t* recv_idx) {
     if (!team || static_cast<Team*>(team)->n != nranks) { set_error("sns_attach_team: bad team"); return SNS_E_ARG; }
-    return attach_common(h, rank, nranks, nullptr, static_cast<Team*>(team), n_owned, n_nbr, nbr, send_ptr, send_idx,
+    return attach_common(h, rank, nranks, nullptr, static_cast<Team*>(team), nullptr, n_owned, n_nbr, nbr, send_ptr, send_idx,
                          recv_ptr, recv_idx);
+}
+
+int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]) {
+    if (!peer_out || window_bytes < 0) return SNS_E_ARG;
+    Peer* p = nullptr;
+    SNS_TRY(peer_create(device, rank, nranks, (size_t)window_bytes, &p, ipc_handle_out));
+    *peer_out = p;
+    return SNS_OK;
+}
+int sns_peer_connect(void* peer, const char* ipc_handles) { return peer_connect(static_cast<Peer*>(peer), ipc_handles); }
+int sns_peer_destroy(void* peer) { return peer_destroy(static_cast<Peer*>(peer)); }
+int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned, int n_nbr, const int32_t* nbr, const int32_t* send_ptr,
+                    const int32_t* send_idx, const int32_t* recv_ptr, const int32_t* recv_idx) {
+    Peer* p = static_cast<Peer*>(peer);
+    if (!p || !p->connected) { set_error("sns_attach_peer: the peer communicator is not connected"); return SNS_E_ARG; }
+    if (h && h->device != p->device) { set_error("sns_attach_peer: handle and window live on different devices"); return SNS_E_ARG; }
+    return attach_common(h, p->rank, p->nranks, nullptr, nullptr, p, n_owned, n_nbr, nbr, send_ptr, send_idx, recv_ptr, recv_idx);
 }
 
 int sns_residual(sns_handle h, int form, const double* w, double* F) {
@@ -3047,7 +3085,7 @@ int sns_comm_info(sns_handle h, int32_t out[4]) {
     out[2] = 1;
     const Comm* c = h->comm.get();
     if (!c) return SNS_OK;
-    out[0] = c->nccl ? 1 : (c->team ? 2 : 0);
+    out[0] = c->nccl ? 1 : (c->team ? 2 : (c->peer ? 3 : 0));
     out[1] = c->rank;
     out[2] = c->nranks;
     if (c->nccl) {

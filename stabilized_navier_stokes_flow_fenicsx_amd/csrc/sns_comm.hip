@@ -1,7 +1,10 @@
-// Transports of sns_comm.h: RCCL over xGMI (product) and the in-process Team (tests).
+// Transports of sns_comm.h: RCCL over xGMI and the direct peer-window transport (product), the in-process Team (tests).
 #include "sns_comm.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "sns_internal.h"
 #include "sns_kernels.h"
@@ -23,6 +26,143 @@ namespace sns {
             set_error(std::string(#expr) + ": " + ncclGetErrorString(_e));                           \
             return SNS_E_COMM;                                                                       \
         }                                                                                            \
+    } while (0)
+
+
+// ---- peer transport: device side ------------------------------------------------------------------------------------------
+// Memory model: the windows are fine-grained device memory; a sender's payload stores are followed by a system-scope fence and
+// a system-scope release store of the sequence flag; a receiver polls the flag with system-scope acquire loads and reads the
+// payload with system-scope loads (never through a stale cache line of an earlier exchange).  Every wait is bounded by the
+// communicator's timeout and reports through the mapped error word instead of spinning for ever.
+namespace {
+
+__device__ __forceinline__ void flag_store(unsigned long long* f, unsigned long long v) {
+    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool flag_wait(const unsigned long long* f, unsigned long long v, long long timeout_ticks,
+                                          int* err, int code) {
+    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return true;
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return true;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;   // someone gave up already
+        if ((long long)wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+__device__ __forceinline__ double sys_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// halo put: the owned values listed in send_idx go straight into the neighbours' receive buffers; the last workgroup to
+// finish raises this rank's flag in every neighbour's window (also across links that carry no payload in this direction: the
+// flag is what keeps a rank from running two exchanges ahead of a neighbour, see comm_exchange)
+__global__ __launch_bounds__(256) void k_peer_put(int32_t ns, int nn, const int32_t* __restrict__ send_idx,
+                                                  const int32_t* __restrict__ send_ptr, const double* __restrict__ x,
+                                                  double* const* __restrict__ put, unsigned long long* const* __restrict__ rflag,
+                                                  unsigned long long seq, unsigned int* __restrict__ done) {
+    __shared__ int32_t sp[PEER_MAX_RANKS + 1];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    if (tid <= nn) sp[tid] = send_ptr[tid];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+    const int32_t i = (int32_t)(t >> 2);
+    const int c = (int)(t & 3);
+    if (i < ns) {
+        int k = 0;
+        while (k + 1 < nn && i >= sp[k + 1]) ++k;
+        put[k][4 * (int64_t)(i - sp[k]) + c] = x[4 * (int64_t)send_idx[i] + c];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (last) {
+        __threadfence_system();
+        if (tid < nn) flag_store(rflag[tid], seq);
+        if (tid == 0) *done = 0u;
+    }
+}
+
+// halo wait + unpack: every workgroup waits for all neighbours' flags, then scatters its part of the receive buffer
+__global__ __launch_bounds__(256) void k_peer_wait_unpack(int32_t nr, int nn, const int32_t* __restrict__ recv_idx,
+                                                          const double* __restrict__ recv_buf,
+                                                          const unsigned long long* __restrict__ flag, unsigned long long seq,
+                                                          double* __restrict__ x, int* err, long long timeout_ticks) {
+    const int tid = threadIdx.x;
+    if (tid < nn) (void)flag_wait(flag + tid, seq, timeout_ticks, err, 1);
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+    const int32_t i = (int32_t)(t >> 2);
+    if (i < nr) x[4 * (int64_t)recv_idx[i] + (t & 3)] = sys_load(recv_buf + t);
+}
+
+// all-reduce (sum) of count <= PEER_AR_MAX doubles, one workgroup: contribution into every rank's slot table, flags, wait for
+// everybody's, sum in rank order (the same bits on every rank)
+__global__ __launch_bounds__(256) void k_peer_allreduce(double* __restrict__ buf, int count, unsigned long long seq, int rank,
+                                                        int nranks, PeerCtl* const* __restrict__ ctl, int* err,
+                                                        long long timeout_ticks) {
+    const int tid = threadIdx.x, par = (int)(seq & 1ull);
+    for (int idx = tid; idx < nranks * count; idx += 256) {
+        const int r = idx / count, i = idx - r * count;
+        ctl[r]->ar_slot[par][rank][i] = buf[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < nranks) {
+        flag_store(&ctl[tid]->ar_flag[rank], seq);
+        (void)flag_wait(&ctl[rank]->ar_flag[tid], seq, timeout_ticks, err, 2);
+    }
+    __syncthreads();
+    if (tid < count) {
+        double s = 0.0;
+        for (int r = 0; r < nranks; ++r) s += sys_load(&ctl[rank]->ar_slot[par][r][tid]);
+        buf[tid] = s;
+    }
+}
+
+// all-gather, put half: workgroup (b, r) copies its share of this rank's m doubles into rank r's staging area; the last
+// workgroup of column r raises the flag there
+__global__ __launch_bounds__(256) void k_peer_ag_put(const double* __restrict__ send, int64_t m, unsigned long long seq, int rank,
+                                                     int64_t stage_doubles, double* const* __restrict__ ag,
+                                                     PeerCtl* const* __restrict__ ctl, unsigned int* __restrict__ done) {
+    __shared__ int last;
+    const int tid = threadIdx.x, r = blockIdx.y;
+    double* __restrict__ dst = ag[r] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)rank * m;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = send[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) last = (atomicAdd(done + r, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence_system();
+        flag_store(&ctl[r]->ag_flag[rank], seq);
+        done[r] = 0u;
+    }
+}
+// all-gather, wait half: workgroup (b, r) waits for rank r's flag and copies r's m doubles from the own staging area
+__global__ __launch_bounds__(256) void k_peer_ag_wait_copy(double* __restrict__ recv, int64_t count, int64_t off, int64_t m,
+                                                           unsigned long long seq, int rank, int64_t stage_doubles,
+                                                           double* const* __restrict__ ag, PeerCtl* const* __restrict__ ctl,
+                                                           int* err, long long timeout_ticks) {
+    const int tid = threadIdx.x, r = blockIdx.y;
+    if (tid == 0) (void)flag_wait(&ctl[rank]->ag_flag[r], seq, timeout_ticks, err, 3);
+    __syncthreads();
+    const double* __restrict__ src = ag[rank] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)r * m;
+    double* __restrict__ dst = recv + (int64_t)r * count + off;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = sys_load(src + i);
+}
+
+}  // namespace
+
+#define CTRY(expr)                                                                                   \
+    do {                                                                                             \
+        int _rc = (expr);                                                                            \
+        if (_rc != SNS_OK) return _rc;                                                               \
     } while (0)
 
 void Team::barrier() {
@@ -53,14 +193,42 @@ void plan_free(Plan& p) {
     if (p.recv_idx) (void)hipFree(p.recv_idx);
     if (p.send_buf) (void)hipFree(p.send_buf);
     if (p.recv_buf) (void)hipFree(p.recv_buf);
+    if (p.d_send_ptr) (void)hipFree(p.d_send_ptr);
+    if (p.d_recv_ptr) (void)hipFree(p.d_recv_ptr);
+    if (p.d_put) (void)hipFree(p.d_put);
+    if (p.d_rflag) (void)hipFree(p.d_rflag);
+    if (p.d_done) (void)hipFree(p.d_done);
     p.send_idx = p.recv_idx = nullptr;
     p.send_buf = p.recv_buf = nullptr;
+    p.d_send_ptr = p.d_recv_ptr = nullptr;
+    p.d_put = nullptr;
+    p.d_rflag = nullptr;
+    p.d_done = nullptr;
 }
 
 int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
     if (!c || !c->active() || c->nranks <= 1) return SNS_OK;
     const int nn = (int)p.nbr.size();
     const int32_t ns = p.n_send(), nr = p.n_recv();
+    if (c->peer) {
+        // Flow control without acknowledgements: the receive buffers are double-buffered by the parity of the plan's sequence
+        // number, and this rank can start exchange s + 2 only after it has seen every neighbour's flag s + 1, which that
+        // neighbour raised after (stream order) it had unpacked exchange s -- the buffer about to be overwritten.
+        Peer* pe = c->peer;
+        if (nn == 0) return SNS_OK;
+        if (!p.d_put) { set_error("peer transport: halo plan was not connected"); return SNS_E_STATE; }
+        CTRY(peer_check(c));
+        Plan& pm = const_cast<Plan&>(p);
+        const unsigned long long seq = ++pm.seq;
+        const int par = (int)(seq & 1ull);
+        const unsigned gp = (unsigned)std::max<int64_t>(1, (4 * (int64_t)ns + 255) / 256);
+        hipLaunchKernelGGL(k_peer_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put + (size_t)par * nn,
+                           p.d_rflag, seq, p.d_done);
+        const unsigned gu = (unsigned)std::max<int64_t>(1, (4 * (int64_t)nr + 255) / 256);
+        hipLaunchKernelGGL(k_peer_wait_unpack, dim3(gu), dim3(256), 0, s, nr, nn, p.recv_idx, p.win_recv[par], p.win_flag, seq, x,
+                           pe->err_dev, pe->timeout_ticks);
+        return SNS_OK;
+    }
     if (ns > 0)
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((4 * (int64_t)ns + 255) / 256)), dim3(256), 0, s, ns, p.send_idx, x,
                            p.send_buf);
@@ -111,6 +279,16 @@ int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
 
 int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t s) {
     if (!c || !c->active()) return SNS_OK;
+    if (c->peer) {
+        Peer* pe = c->peer;
+        CTRY(peer_check(c));
+        for (int off = 0; off < count; off += PEER_AR_MAX) {
+            const int m = std::min(PEER_AR_MAX, count - off);
+            hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, ++pe->ar_seq, pe->rank, pe->nranks,
+                               pe->d_ctl, pe->err_dev, pe->timeout_ticks);
+        }
+        return SNS_OK;
+    }
     if (c->nccl) {                                           // also with one rank: keeps the RCCL path exercised
         CNCCL(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->nccl, s));
         return SNS_OK;
@@ -135,6 +313,21 @@ int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStre
         CHIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return SNS_OK;
     }
+    if (c->peer) {
+        Peer* pe = c->peer;
+        CTRY(peer_check(c));
+        const int64_t per = (int64_t)(pe->ag_doubles / (size_t)pe->nranks);          // doubles per rank and chunk
+        for (int64_t off = 0; off < count; off += per) {
+            const int64_t m = std::min<int64_t>(per, count - off);
+            const unsigned long long seq = ++pe->ag_seq;
+            const unsigned gb = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
+            hipLaunchKernelGGL(k_peer_ag_put, dim3(gb, pe->nranks), dim3(256), 0, s, send + off, m, seq, pe->rank,
+                               (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->d_done);
+            hipLaunchKernelGGL(k_peer_ag_wait_copy, dim3(gb, pe->nranks), dim3(256), 0, s, recv, (int64_t)count, off, m, seq,
+                               pe->rank, (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->err_dev, pe->timeout_ticks);
+        }
+        return SNS_OK;
+    }
     if (c->nccl) {
         CNCCL(ncclAllGather(send, recv, count, ncclDouble, c->nccl, s));
         return SNS_OK;
@@ -150,6 +343,172 @@ int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStre
     t->barrier();
     CHIP(hipMemcpyAsync(recv, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice, s));
     CHIP(hipStreamSynchronize(s));
+    return SNS_OK;
+}
+
+// ---- peer transport: host side ----------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t PEER_CTL_BYTES = (sizeof(PeerCtl) + 4095) / 4096 * 4096;
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+int peer_create(int device, int rank, int nranks, size_t window_bytes, Peer** out, char handle_out[64]) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+    if (!out || !handle_out || nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) {
+        set_error("sns_peer_create: bad arguments (at most " + std::to_string(PEER_MAX_RANKS) + " ranks)");
+        return SNS_E_ARG;
+    }
+    if (window_bytes == 0) window_bytes = (size_t)64 << 20;
+    if (window_bytes < ((size_t)4 << 20)) { set_error("sns_peer_create: window below 4 MiB"); return SNS_E_ARG; }
+    CHIP(hipSetDevice(device));
+    std::unique_ptr<Peer> p(new Peer);
+    p->rank = rank;
+    p->nranks = nranks;
+    p->device = device;
+    p->bytes = window_bytes;
+    void* w = nullptr;
+    // fine-grained: stores of another GPU become visible to a running kernel of this one (SNS_PEER_WINDOW=uncached | plain for
+    // experiments; "plain" is only right when all ranks share one GPU)
+    const char* kind = std::getenv("SNS_PEER_WINDOW");
+    if (kind && std::strcmp(kind, "plain") == 0) CHIP(hipMalloc(&w, window_bytes));
+    else if (kind && std::strcmp(kind, "uncached") == 0) CHIP(hipExtMallocWithFlags(&w, window_bytes, hipDeviceMallocUncached));
+    else CHIP(hipExtMallocWithFlags(&w, window_bytes, hipDeviceMallocFinegrained));
+    p->base[rank] = static_cast<char*>(w);
+    CHIP(hipMemset(w, 0, window_bytes));
+    CHIP(hipDeviceSynchronize());
+    // control area | all-gather staging (2 parities, a quarter of the window each at most 32 MiB) | plan area
+    p->ag_off = PEER_CTL_BYTES;
+    const size_t ag_bytes = std::min<size_t>((size_t)32 << 20, window_bytes / 4) / (8 * (size_t)nranks) * (8 * (size_t)nranks);
+    p->ag_doubles = ag_bytes / 8;
+    p->bump = align_up(p->ag_off + 2 * ag_bytes, 4096);
+    CHIP(hipHostMalloc((void**)&p->err_host, sizeof(int), hipHostMallocMapped));
+    *p->err_host = 0;
+    CHIP(hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0));
+    CHIP(hipMalloc((void**)&p->d_done, PEER_MAX_RANKS * sizeof(unsigned int)));
+    CHIP(hipMemset(p->d_done, 0, PEER_MAX_RANKS * sizeof(unsigned int)));
+    double ms = 20000.0;
+    if (const char* t = std::getenv("SNS_PEER_TIMEOUT_MS")) ms = std::max(1.0, std::atof(t));
+    p->timeout_ticks = (long long)(ms * 1.0e5);                                  // wall_clock64(): 100 MHz
+    hipIpcMemHandle_t hd;
+    CHIP(hipIpcGetMemHandle(&hd, w));
+    std::memcpy(handle_out, &hd, 64);
+    *out = p.release();
+    return SNS_OK;
+}
+
+int peer_connect(Peer* p, const char* handles) {
+    if (!p || !handles) return SNS_E_ARG;
+    if (p->connected) { set_error("sns_peer_connect: already connected"); return SNS_E_STATE; }
+    CHIP(hipSetDevice(p->device));
+    for (int r = 0; r < p->nranks; ++r) {
+        if (r == p->rank) continue;
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, handles + (size_t)64 * r, 64);
+        void* w = nullptr;
+        CHIP(hipIpcOpenMemHandle(&w, hd, hipIpcMemLazyEnablePeerAccess));
+        p->base[r] = static_cast<char*>(w);
+        p->mapped[r] = true;
+    }
+    std::vector<PeerCtl*> ctl((size_t)p->nranks);
+    std::vector<double*> ag((size_t)p->nranks);
+    for (int r = 0; r < p->nranks; ++r) {
+        ctl[(size_t)r] = reinterpret_cast<PeerCtl*>(p->base[r]);
+        ag[(size_t)r] = reinterpret_cast<double*>(p->base[r] + p->ag_off);
+    }
+    CHIP(hipMalloc((void**)&p->d_ctl, ctl.size() * sizeof(PeerCtl*)));
+    CHIP(hipMalloc((void**)&p->d_ag, ag.size() * sizeof(double*)));
+    CHIP(hipMemcpy(p->d_ctl, ctl.data(), ctl.size() * sizeof(PeerCtl*), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(p->d_ag, ag.data(), ag.size() * sizeof(double*), hipMemcpyHostToDevice));
+    p->connected = true;
+    return SNS_OK;
+}
+
+int peer_destroy(Peer* p) {
+    if (!p) return SNS_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < p->nranks; ++r)
+        if (p->mapped[r] && p->base[r]) (void)hipIpcCloseMemHandle(p->base[r]);
+    if (p->base[p->rank]) (void)hipFree(p->base[p->rank]);
+    if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_ag) (void)hipFree(p->d_ag);
+    if (p->d_done) (void)hipFree(p->d_done);
+    if (p->err_host) (void)hipHostFree(p->err_host);
+    delete p;
+    return SNS_OK;
+}
+
+int peer_check(Comm* c) {
+    if (!c || !c->peer) return SNS_OK;
+    const int e = *reinterpret_cast<volatile int*>(c->peer->err_host);
+    if (e == 0) return SNS_OK;
+    static const char* what[] = {"", "halo exchange", "all-reduce", "all-gather"};
+    set_error(std::string("peer transport: rank ") + std::to_string(c->rank) + " gave up waiting in a(n) " +
+              what[(e >= 1 && e <= 3) ? e : 0] + " (a peer is late by more than SNS_PEER_TIMEOUT_MS, or gone)");
+    return SNS_E_COMM;
+}
+
+// Receive buffers and flags of a plan are carved from this rank's window; the offsets a neighbour must write to are offered
+// through one host all-gather (3 doubles per rank pair), after which every rank can compute the remote addresses.
+int peer_plan_offer(Comm* c, Plan& p, PlanOffers& t) {
+    Peer* pe = c->peer;
+    const int nr_ranks = pe->nranks, nn = (int)p.nbr.size();
+    if (!pe->connected) { set_error("peer transport: sns_peer_connect has not been called"); return SNS_E_STATE; }
+    t.mine.assign((size_t)3 * nr_ranks, -1.0);
+    const size_t flag_off = align_up(pe->bump, 256);
+    const size_t rbytes = align_up(std::max<size_t>(32, (size_t)p.n_recv() * 32), 256);
+    const size_t r0 = align_up(flag_off + (size_t)std::max(1, nn) * 8, 256), r1 = r0 + rbytes, end = r1 + rbytes;
+    if (end > pe->bytes) {
+        set_error("peer transport: window of " + std::to_string(pe->bytes >> 20) + " MiB exhausted (sns_peer_create window_bytes)");
+        return SNS_E_COMM;
+    }
+    pe->bump = end;
+    char* own = pe->base[pe->rank];
+    p.win_flag = reinterpret_cast<unsigned long long*>(own + flag_off);
+    p.win_recv[0] = reinterpret_cast<double*>(own + r0);
+    p.win_recv[1] = reinterpret_cast<double*>(own + r1);
+    p.seq = 0;
+    for (int k = 0; k < nn; ++k) {
+        const int j = p.nbr[(size_t)k];
+        if (j < 0 || j >= nr_ranks || j == pe->rank) continue;                    // (check_plan_symmetry reports it)
+        t.mine[(size_t)3 * j + 0] = (double)(r0 + (size_t)32 * p.recv_ptr[(size_t)k]);
+        t.mine[(size_t)3 * j + 1] = (double)(r1 + (size_t)32 * p.recv_ptr[(size_t)k]);
+        t.mine[(size_t)3 * j + 2] = (double)(flag_off + (size_t)8 * k);
+    }
+    return SNS_OK;
+}
+
+int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t) {
+    Peer* pe = c->peer;
+    const int nr_ranks = pe->nranks, nn = (int)p.nbr.size();
+    if (t.all.size() != (size_t)3 * nr_ranks * nr_ranks) { set_error("peer transport: bad offer table"); return SNS_E_COMM; }
+    if (nn > PEER_MAX_RANKS) { set_error("peer transport: too many neighbours"); return SNS_E_ARG; }
+    std::vector<double*> put((size_t)2 * std::max(1, nn), nullptr);
+    std::vector<unsigned long long*> rflag((size_t)std::max(1, nn), nullptr);
+    for (int k = 0; k < nn; ++k) {
+        const int j = p.nbr[(size_t)k];
+        const double* o = t.all.data() + ((size_t)j * nr_ranks + pe->rank) * 3;   // what rank j offers to this rank
+        if (o[0] < 0.0 || o[1] < 0.0 || o[2] < 0.0) {
+            set_error("peer transport: rank " + std::to_string(j) + " does not list rank " + std::to_string(pe->rank) + " as a neighbour");
+            return SNS_E_COMM;
+        }
+        put[(size_t)k] = reinterpret_cast<double*>(pe->base[j] + (size_t)o[0]);
+        put[(size_t)nn + k] = reinterpret_cast<double*>(pe->base[j] + (size_t)o[1]);
+        rflag[(size_t)k] = reinterpret_cast<unsigned long long*>(pe->base[j] + (size_t)o[2]);
+    }
+    std::vector<int32_t> sp(p.send_ptr), rp(p.recv_ptr);
+    if (sp.empty()) sp.assign(1, 0);
+    if (rp.empty()) rp.assign(1, 0);
+    CHIP(hipMalloc((void**)&p.d_send_ptr, sp.size() * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&p.d_recv_ptr, rp.size() * sizeof(int32_t)));
+    CHIP(hipMemcpy(p.d_send_ptr, sp.data(), sp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(p.d_recv_ptr, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CHIP(hipMalloc((void**)&p.d_put, put.size() * sizeof(double*)));
+    CHIP(hipMalloc((void**)&p.d_rflag, rflag.size() * sizeof(unsigned long long*)));
+    CHIP(hipMemcpy(p.d_put, put.data(), put.size() * sizeof(double*), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(p.d_rflag, rflag.data(), rflag.size() * sizeof(unsigned long long*), hipMemcpyHostToDevice));
+    CHIP(hipMalloc((void**)&p.d_done, sizeof(unsigned int)));
+    CHIP(hipMemset(p.d_done, 0, sizeof(unsigned int)));
     return SNS_OK;
 }
 

@@ -217,6 +217,9 @@ def gather_owned(part: LocalPart, x_local, n_global_nodes: int, group=None):
     """All ranks obtain the global dof vector from the owned parts (all_gather; setup/IO only)."""
     import torch
     import torch.distributed as dist
+    out_device = x_local.device
+    if dist.get_backend(group) == "gloo":          # (peer-window runs bootstrap over gloo: host tensors for this setup / IO gather)
+        x_local = x_local.cpu()
     own = x_local.view(-1, 4)[: part.n_owned].contiguous()
     ids = torch.as_tensor(part.l2g[: part.n_owned], dtype=torch.long, device=x_local.device)
     counts = [torch.zeros(1, dtype=torch.long, device=x_local.device) for _ in range(part.nranks)]
@@ -233,4 +236,4 @@ def gather_owned(part: LocalPart, x_local, n_global_nodes: int, group=None):
     out = torch.zeros((n_global_nodes, 4), dtype=x_local.dtype, device=x_local.device)
     for c, v, i in zip(counts, vs, is_):
         out[i[: int(c)]] = v[: int(c)]
-    return out.view(-1)
+    return out.view(-1).to(out_device)

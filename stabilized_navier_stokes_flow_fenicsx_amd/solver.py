@@ -112,7 +112,10 @@ class FlowProblem:
         communicator of the C-ABI is bootstrapped through torch.distributed."""
         import torch.distributed as dist
         from . import partition as PT
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if isinstance(group, PeerGroup):
+            rank, world = group.rank, group.nranks
+        else:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
         mask, g = bcs.flatten() if isinstance(bcs, DirichletSet) else bcs
         owner = PT.rcb_partition(mesh.points, world)
         part = PT.build_local_part(mesh, mask, g, owner, rank, world)
@@ -142,6 +145,14 @@ class FlowProblem:
                 check(self.lib.sns_attach_team(self.h, group.ptr, part.rank, part.nranks, part.n_owned, len(nb),
                                                nb.ctypes.data, sp_.ctypes.data, si.ctypes.data, rp.ctypes.data,
                                                ri.ctypes.data))
+            self.n_owned = part.n_owned
+            return
+        if isinstance(group, PeerGroup):               # one process per GPU of one node, peer windows over xGMI
+            if (group.rank, group.nranks) != (part.rank, part.nranks):
+                raise ValueError("partition and peer communicator disagree about rank / ranks")
+            with torch.cuda.device(self.device):
+                check(self.lib.sns_attach_peer(self.h, group.ptr, part.n_owned, len(nb), nb.ctypes.data, sp_.ctypes.data,
+                                               si.ctypes.data, rp.ctypes.data, ri.ctypes.data))
             self.n_owned = part.n_owned
             return
         if group == "local-only":                      # tests: owned/ghost split without a communicator
@@ -177,7 +188,7 @@ class FlowProblem:
             out.view(-1, 4)[torch.as_tensor(self.part.l2g, device=x_local.device)] = x_local.view(-1, 4)
             return out
         ng = self.global_mesh.num_nodes if self.global_mesh is not None else self.n_global_nodes
-        return PT.gather_owned(self.part, x_local, ng, self.group)
+        return PT.gather_owned(self.part, x_local, ng, self.group.dist_group if isinstance(self.group, PeerGroup) else self.group)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
@@ -327,7 +338,7 @@ class FlowProblem:
         """Transport / rank / ranks of the handle's communicator; ``rccl_ranks`` is what ncclCommCount reports."""
         c = (C.c_int32 * 4)()
         check(self.lib.sns_comm_info(self.h, c))
-        return dict(transport={0: "none", 1: "rccl", 2: "team"}[c[0]], rank=c[1], nranks=c[2], rccl_ranks=c[3])
+        return dict(transport={0: "none", 1: "rccl", 2: "team", 3: "peer"}[c[0]], rank=c[1], nranks=c[2], rccl_ranks=c[3])
 
     def hierarchy(self):
         """The AMG hierarchy as built: one dict per level (rows, 4x4 blocks, sweeps per half cycle, block-Jacobi damping)."""
@@ -360,6 +371,45 @@ class FlowProblem:
         ms = C.c_double()
         check(self.lib.sns_bench_assemble(self.h, _FORMS[form], _ptr(w), _ptr(F), reps, C.byref(ms)))
         return ms.value
+
+
+class PeerGroup:
+    """Peer-window communicator of the C-ABI (sns_peer_*): one process per GPU of one node, the collectives of the solver are
+    stores into the other ranks' IPC-mapped windows -- no RCCL in the data path.  The 64-byte IPC handles are exchanged through
+    ``torch.distributed`` (any backend: gloo is enough, nothing but this bootstrap and ``close`` goes through it).
+
+        dist.init_process_group(...)
+        peers = PeerGroup(device="cuda:0")                 # collective
+        P = FlowProblem.distributed(mesh, bcs, group=peers)
+        ...
+        P.close(); peers.close()                           # collective
+    """
+
+    def __init__(self, device=None, *, group=None, window_bytes: int = 0):
+        import torch.distributed as dist
+        self.lib = _lib.load()
+        self.dist_group = group
+        self.rank, self.nranks = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}"
+        self.device = torch.device(device)
+        p = C.c_void_p()
+        hd = C.create_string_buffer(64)
+        check(self.lib.sns_peer_create(self.device.index or 0, self.rank, self.nranks, int(window_bytes), C.byref(p), hd))
+        self.ptr = p
+        box = [None] * self.nranks
+        dist.all_gather_object(box, bytes(hd.raw), group=group)          # (implies: every window exists and is zeroed)
+        check(self.lib.sns_peer_connect(self.ptr, b"".join(box)))
+        dist.barrier(group=group)                                        # every rank has mapped every window
+
+    def close(self):
+        """Collective; call after the problems attached to this communicator are closed."""
+        if self.ptr:
+            import torch.distributed as dist
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.dist_group)                          # nobody stores into a window that is about to go
+            self.lib.sns_peer_destroy(self.ptr)
+            self.ptr = None
 
 
 class Team:

@@ -1,0 +1,102 @@
+"""Round 4: the peer-window transport (sns_peer_*, csrc/sns_comm.hip) between real processes.
+
+RCCL cannot put two ranks on one GPU, so until now the partitioned solver had only run with ranks = threads of one process (the
+Team emulation).  The peer transport needs nothing but HIP IPC: here every rank is a PROCESS with its own HIP context, the ranks
+map each other's windows, and halo exchange / all-reduce / all-gather are the production kernels (stores into the peer's window,
+sequence flags, bounded waits).  All ranks share the box's one GPU, so the xGMI hop itself is the only thing not exercised.
+
+What is checked, per rank, against the serial solve of the same problem (the Team tests' bounds): SpMV with halo exchange 1e-12,
+Stokes 1e-6, Newton fields 1e-8, identical iteration counts and decisions on every rank; and that a rank which never joins a
+collective turns into SNS_E_COMM on the others after SNS_PEER_TIMEOUT_MS instead of a hang.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(kind, world, tmp_path, env_extra=None, deadline=420.0):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    port = _free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    procs, outs, logs = [], [], []
+    for r in range(world):
+        o = str(tmp_path / f"rank{r}.json")
+        lg = open(str(tmp_path / f"rank{r}.log"), "w")
+        outs.append(o)
+        logs.append(lg)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "peer_worker.py"), str(r), str(world), str(port), kind, o],
+                                      stdout=lg, stderr=subprocess.STDOUT, env=env))
+    t0 = time.time()
+    try:
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - (time.time() - t0)))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                      # exactly the processes started above
+        for p in procs:
+            p.wait()
+        tails = [open(str(tmp_path / f"rank{r}.log")).read()[-1500:] for r in range(world)]
+        pytest.fail(f"peer ranks did not finish within {deadline:.0f} s\n" + "\n---\n".join(tails))
+    finally:
+        for lg in logs:
+            lg.close()
+    res = []
+    for r in range(world):
+        if not os.path.exists(outs[r]):
+            pytest.fail(f"rank {r} left no result (exit {procs[r].returncode}):\n" + open(str(tmp_path / f"rank{r}.log")).read()[-3000:])
+        res.append(json.load(open(outs[r])))
+    return res
+
+
+@pytest.mark.parametrize("kind,world", [("duct", 3), ("duct-rep-dense", 3), ("cavity", 4)])
+def test_partitioned_solve_between_processes_over_peer_windows(kind, world, tmp_path):
+    res = _run_ranks(kind, world, tmp_path)
+    for r in res:
+        assert r["ok"], r
+    print("  " + kind + ": " + "; ".join(f"rank {r['rank']}: {r['n_owned']} nodes, nbrs {r['neighbors']}, stokes {r['stokes_its']} its, "
+                                       f"ksp {r['ksp_its']}, {r['exchanges']} exchanges, {r['allreduces']} all-reduces, {r['seconds']:.1f} s"
+                                       for r in res))
+    r0 = res[0]
+    for r in res:
+        assert r["transport"] == "peer" and r["nranks"] == world
+        assert r["err_spmv"] < 1e-12 and r["err_stokes"] < 1e-6 and r["err_newton"] < 1e-8, r
+        assert r["stokes_reason"] > 0 and r["newton_reason"] == r["serial"]["newton_reason"] and r["newton_its"] == r["serial"]["newton_its"]
+        assert (r["stokes_its"], r["ksp_its"], r["levels"]) == (r0["stokes_its"], r0["ksp_its"], r0["levels"])   # same decisions everywhere
+        assert r["stokes_its"] <= 2 * r["serial"]["stokes_its"] + 4
+    if kind == "duct-rep-dense":
+        assert r0["levels"] == 2                               # fine level + the replicated, directly solved level 1
+    if kind == "cavity":
+        assert max(len(r["neighbors"]) for r in res) == 3
+
+
+def test_a_rank_that_never_arrives_is_an_error_not_a_hang(tmp_path):
+    res = _run_ranks("duct-late", 3, tmp_path, env_extra={"SNS_PEER_TIMEOUT_MS": "3000"}, deadline=300.0)
+    late = [r for r in res if r.get("skipped")]
+    waited = [r for r in res if not r.get("skipped")]
+    assert len(late) == 1 and len(waited) == 2
+    for r in waited:
+        assert not r["ok"] and "peer transport" in r.get("sns_error", "") and "gave up waiting" in r["sns_error"], r
+        assert r["seconds"] < 60.0
