@@ -276,6 +276,11 @@ int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
 int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]);
 int sns_peer_connect(void* peer, const char* ipc_handles);
 int sns_peer_destroy(void* peer);
+/* Self-test and latency probe of the protocol inside ONE process: nranks (2 or 3) threads with a window, a stream and a
+ * communicator end each, wired directly (no IPC), a ring of halo links of `halo_nodes` nodes per direction.  Per collective -- halo
+ * exchange, all-reduce (4 doubles), all-gather (2048 doubles per rank) -- `reps` rounds with every payload verified, then `reps`
+ * timed rounds of the collective alone: us_out = microseconds per round (max over ranks).  SNS_E_COMM on a wrong value or a timeout. */
+int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
 int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
@@ -370,6 +375,10 @@ int sns_get_kernel_times(sns_handle h, double ms_total[8], int64_t calls[8]);
  * the average duration in ms.                                                  */
 int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
 int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
+/* one collective of the attached communicator, `reps` times back to back (COLLECTIVE: every rank calls it with the same arguments):
+ * which 0 = halo exchange of the assembled operator's plan, 1 = all-reduce of `count` (1..32) doubles, 2 = all-gather of `count`
+ * doubles per rank.  Any transport.                                                                                          */
+int sns_bench_collective(sns_handle h, int which, int count, int reps, double* ms_avg);
 /* ---- batched particle tracing (next row after the solve path; replaces the per-seed
  *      solve_ivp(RK45) of NavierStokes/streamtrace.py:208-232, :357-383) ---------------
  * One lane per seed: scipy's RK45 (same tableau, controller and initial step; rtol/atol as

@@ -91,6 +91,7 @@ _SIGNATURES = [
     ("sns_peer_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(_P), C.c_char_p]),
     ("sns_peer_connect", C.c_int, [_P, C.c_char_p]),
     ("sns_peer_destroy", C.c_int, [_P]),
+    ("sns_peer_selftest", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("sns_attach_peer", C.c_int, [_H, _P, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
     ("sns_residual", C.c_int, [_H, C.c_int, _P, _P]),
     ("sns_jacobian", C.c_int, [_H, C.c_int, _P, _P]),
@@ -116,6 +117,7 @@ _SIGNATURES = [
     ("sns_get_kernel_times", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("sns_bench_spmv", C.c_int, [_H, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     ("sns_bench_assemble", C.c_int, [_H, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_double)]),
+    ("sns_bench_collective", C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("sns_streamtrace", C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),

@@ -236,7 +236,8 @@ int reduce_to(sns_ctx* h, int nblocks, int nred, double* dst_dev);
 template <int WHICH>
 int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
     constexpr int NRED = WHICH == 1 ? 1 : 5;
-    if (h->comm && h->comm->active()) {
+    Peer* pe = (h->comm && h->comm->active()) ? h->comm->peer : nullptr;
+    if (h->comm && h->comm->active() && !pe) {
         SNS_TRY(reduce_to(h, nblocks, NRED, red));
         if (WHICH == 1) hipLaunchKernelGGL(k_bicg_alpha, dim3(1), dim3(64), 0, h->stream, sc, red);
         else hipLaunchKernelGGL(k_bicg_omega, dim3(1), dim3(64), 0, h->stream, sc, red);
@@ -252,6 +253,13 @@ int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
             src = h->partial2;
             nb = nchunks;
         }
+    }
+    if (pe) {                                    // peer windows: the all-reduce rides inside the same single-workgroup launch
+        SNS_TRY(peer_check(h->comm.get()));
+        ++h->ctr_allreduce;
+        hipLaunchKernelGGL((k_reduce_final_bicg_peer<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc,
+                           peer_next_allreduce(pe));
+        return SNS_OK;
     }
     hipLaunchKernelGGL((k_reduce_final_bicg<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc);
     return SNS_OK;
@@ -2870,6 +2878,9 @@ int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void
 }
 int sns_peer_connect(void* peer, const char* ipc_handles) { return peer_connect(static_cast<Peer*>(peer), ipc_handles); }
 int sns_peer_destroy(void* peer) { return peer_destroy(static_cast<Peer*>(peer)); }
+int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]) {
+    return peer_selftest(device, nranks, halo_nodes, reps, us_out);
+}
 int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned, int n_nbr, const int32_t* nbr, const int32_t* send_ptr,
                     const int32_t* send_idx, const int32_t* recv_ptr, const int32_t* recv_idx) {
     Peer* p = static_cast<Peer*>(peer);
@@ -3254,6 +3265,47 @@ int sns_bench_assemble(sns_handle h, int form, const double* w, double* F, int r
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_avg = ms / reps;
     return SNS_OK;
+}
+int sns_bench_collective(sns_handle h, int which, int count, int reps, double* ms_avg) {
+    if (!h || reps <= 0 || !ms_avg || count < 0) return SNS_E_ARG;
+    Comm* c = h->comm.get();
+    if (!c || !c->active()) { set_error("sns_bench_collective: no communicator attached"); return SNS_E_STATE; }
+    double *snd = nullptr, *rcv = nullptr;
+    if (which == 0) {
+        if (c->plans.empty() || !h->levels[0].xg) { set_error("sns_bench_collective: no level-0 halo plan"); return SNS_E_STATE; }
+    } else if (which == 1) {
+        if (count < 1 || count > 32) { set_error("sns_bench_collective: all-reduce of 1..32 doubles"); return SNS_E_ARG; }
+        HIP_TRY(hipMemsetAsync(h->d_scal + 64, 0, 32 * sizeof(double), h->stream));
+    } else if (which == 2) {
+        SNS_TRY(dev_alloc(&snd, (size_t)std::max(1, count)));
+        SNS_TRY(dev_alloc(&rcv, (size_t)std::max(1, count) * c->nranks));
+        HIP_TRY(hipMemset(snd, 0, (size_t)std::max(1, count) * sizeof(double)));
+    } else {
+        return SNS_E_ARG;
+    }
+    auto one = [&]() -> int {
+        if (which == 0) return comm_exchange(c, c->plans[0], h->levels[0].xg, h->stream);
+        if (which == 1) return comm_allreduce_sum(c, h->d_scal + 64, count, h->stream);
+        return comm_allgather(c, snd, rcv, count, h->stream);
+    };
+    int rc = SNS_OK;
+    for (int i = 0; i < 5 && rc == SNS_OK; ++i) rc = one();
+    if (rc == SNS_OK) {
+        (void)hipEventRecord(h->ev0, h->stream);
+        for (int i = 0; i < reps && rc == SNS_OK; ++i) rc = one();
+        (void)hipEventRecord(h->ev1, h->stream);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    if (rc == SNS_OK) rc = peer_check(c);
+    if (rc == SNS_OK) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) rc = SNS_E_HIP;
+        *ms_avg = ms / reps;
+    }
+    if (which == 0) (void)hipMemset(h->levels[0].xg, 0, 4 * (size_t)h->levels[0].n * sizeof(double));   // (the cycle relies on zero ghosts there)
+    if (snd) (void)hipFree(snd);
+    if (rcv) (void)hipFree(rcv);
+    return rc;
 }
 
 }  // extern "C"

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include "sns_peer_dev.h"
+
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -28,16 +30,6 @@
 #include <vector>
 
 namespace sns {
-
-constexpr int PEER_MAX_RANKS = 16;               // ranks of a peer communicator (one node)
-constexpr int PEER_AR_MAX = 32;                  // doubles per all-reduce launch
-
-// Control area at the start of every window -- same layout on every rank, written by the peers (slot [r] by rank r only).
-struct PeerCtl {
-    unsigned long long ar_flag[PEER_MAX_RANKS];              // sequence number of rank r's latest all-reduce contribution
-    unsigned long long ag_flag[PEER_MAX_RANKS];              // ... all-gather contribution
-    double ar_slot[2][PEER_MAX_RANKS][PEER_AR_MAX];          // contributions, by parity of the sequence number
-};
 
 struct Peer {                                    // one rank's end of the direct transport (sns_peer_create / _connect)
     int rank = 0, nranks = 1, device = 0;
@@ -108,7 +100,10 @@ int comm_allgather(Comm* c, const double* send_dev, double* recv_dev, int count,
 // peer transport
 int peer_create(int device, int rank, int nranks, size_t window_bytes, Peer** out, char ipc_handle_out[64]);
 int peer_connect(Peer* p, const char* handles /* nranks x 64 bytes, rank order */);
+int peer_finish_connect(Peer* p);               // (second half of peer_connect: device tables from base[])
 int peer_destroy(Peer* p);
+// in-process self-test + latency probe: nranks threads, a ring of halo links; us_out = {exchange, all-reduce, all-gather} per round
+int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
 // wire a freshly uploaded plan to the neighbours' windows.  `table_allgather(mine, all)` is the caller's host all-gather of
 // 3 * nranks doubles per rank (collective: every rank connects the same plan at the same time).
 struct PlanOffers {                              // where rank j writes in MY window: payload parity 0 / 1, flag; -1 = no link
@@ -117,5 +112,6 @@ struct PlanOffers {                              // where rank j writes in MY wi
 int peer_plan_offer(Comm* c, Plan& p, PlanOffers& t);
 int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t);
 int peer_check(Comm* c);                         // SNS_E_COMM once a device-side wait has timed out
+PeerArgs peer_next_allreduce(Peer* p);           // arguments of the next all-reduce round (for a kernel that carries it inside)
 
 }  // namespace sns

@@ -2,9 +2,11 @@
 #include "sns_comm.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "sns_internal.h"
 #include "sns_kernels.h"
@@ -36,27 +38,6 @@ namespace sns {
 // communicator's timeout and reports through the mapped error word instead of spinning for ever.
 namespace {
 
-__device__ __forceinline__ void flag_store(unsigned long long* f, unsigned long long v) {
-    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ bool flag_wait(const unsigned long long* f, unsigned long long v, long long timeout_ticks,
-                                          int* err, int code) {
-    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return true;
-    const long long t0 = (long long)wall_clock64();
-    for (;;) {
-        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return true;
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;   // someone gave up already
-        if ((long long)wall_clock64() - t0 > timeout_ticks) {
-            __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-__device__ __forceinline__ double sys_load(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // halo put: the owned values listed in send_idx go straight into the neighbours' receive buffers; the last workgroup to
 // finish raises this rank's flag in every neighbour's window (also across links that carry no payload in this direction: the
 // flag is what keeps a rank from running two exchanges ahead of a neighbour, see comm_exchange)
@@ -69,13 +50,14 @@ __global__ __launch_bounds__(256) void k_peer_put(int32_t ns, int nn, const int3
     const int tid = threadIdx.x;
     if (tid <= nn) sp[tid] = send_ptr[tid];
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + tid;
-    const int32_t i = (int32_t)(t >> 2);
-    const int c = (int)(t & 3);
+    const int64_t t = (int64_t)blockIdx.x * 256 + tid;        // one lane per half node: 16-byte loads and stores
+    const int32_t i = (int32_t)(t >> 1);
+    const int hh = (int)(t & 1);
     if (i < ns) {
         int k = 0;
         while (k + 1 < nn && i >= sp[k + 1]) ++k;
-        put[k][4 * (int64_t)(i - sp[k]) + c] = x[4 * (int64_t)send_idx[i] + c];
+        const double2 v = *reinterpret_cast<const double2*>(x + 4 * (int64_t)send_idx[i] + 2 * hh);
+        *reinterpret_cast<double2*>(put[k] + 4 * (int64_t)(i - sp[k]) + 2 * hh) = v;
     }
     __threadfence_system();
     __syncthreads();
@@ -83,7 +65,7 @@ __global__ __launch_bounds__(256) void k_peer_put(int32_t ns, int nn, const int3
     __syncthreads();
     if (last) {
         __threadfence_system();
-        if (tid < nn) flag_store(rflag[tid], seq);
+        if (tid < nn) peer_flag_store(rflag[tid], seq);
         if (tid == 0) *done = 0u;
     }
 }
@@ -94,35 +76,21 @@ __global__ __launch_bounds__(256) void k_peer_wait_unpack(int32_t nr, int nn, co
                                                           const unsigned long long* __restrict__ flag, unsigned long long seq,
                                                           double* __restrict__ x, int* err, long long timeout_ticks) {
     const int tid = threadIdx.x;
-    if (tid < nn) (void)flag_wait(flag + tid, seq, timeout_ticks, err, 1);
+    if (tid < nn) (void)peer_flag_wait(flag + tid, seq, timeout_ticks, err, 1);
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + tid;
-    const int32_t i = (int32_t)(t >> 2);
-    if (i < nr) x[4 * (int64_t)recv_idx[i] + (t & 3)] = sys_load(recv_buf + t);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");             // every lane: nothing older than the flags is read below
+    const int64_t t = (int64_t)blockIdx.x * 256 + tid;        // one lane per half node
+    const int32_t i = (int32_t)(t >> 1);
+    if (i < nr) {
+        const double2 v = *reinterpret_cast<const double2*>(recv_buf + 2 * t);
+        *reinterpret_cast<double2*>(x + 4 * (int64_t)recv_idx[i] + 2 * (t & 1)) = v;
+    }
 }
 
 // all-reduce (sum) of count <= PEER_AR_MAX doubles, one workgroup: contribution into every rank's slot table, flags, wait for
 // everybody's, sum in rank order (the same bits on every rank)
-__global__ __launch_bounds__(256) void k_peer_allreduce(double* __restrict__ buf, int count, unsigned long long seq, int rank,
-                                                        int nranks, PeerCtl* const* __restrict__ ctl, int* err,
-                                                        long long timeout_ticks) {
-    const int tid = threadIdx.x, par = (int)(seq & 1ull);
-    for (int idx = tid; idx < nranks * count; idx += 256) {
-        const int r = idx / count, i = idx - r * count;
-        ctl[r]->ar_slot[par][rank][i] = buf[i];
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < nranks) {
-        flag_store(&ctl[tid]->ar_flag[rank], seq);
-        (void)flag_wait(&ctl[rank]->ar_flag[tid], seq, timeout_ticks, err, 2);
-    }
-    __syncthreads();
-    if (tid < count) {
-        double s = 0.0;
-        for (int r = 0; r < nranks; ++r) s += sys_load(&ctl[rank]->ar_slot[par][r][tid]);
-        buf[tid] = s;
-    }
+__global__ __launch_bounds__(256) void k_peer_allreduce(double* __restrict__ buf, int count, PeerArgs a) {
+    peer_allreduce_block(buf, count, a);
 }
 
 // all-gather, put half: workgroup (b, r) copies its share of this rank's m doubles into rank r's staging area; the last
@@ -140,7 +108,7 @@ __global__ __launch_bounds__(256) void k_peer_ag_put(const double* __restrict__ 
     __syncthreads();
     if (last && tid == 0) {
         __threadfence_system();
-        flag_store(&ctl[r]->ag_flag[rank], seq);
+        peer_flag_store(&ctl[r]->ag_flag[rank], seq);
         done[r] = 0u;
     }
 }
@@ -150,11 +118,12 @@ __global__ __launch_bounds__(256) void k_peer_ag_wait_copy(double* __restrict__ 
                                                            double* const* __restrict__ ag, PeerCtl* const* __restrict__ ctl,
                                                            int* err, long long timeout_ticks) {
     const int tid = threadIdx.x, r = blockIdx.y;
-    if (tid == 0) (void)flag_wait(&ctl[rank]->ag_flag[r], seq, timeout_ticks, err, 3);
+    if (tid == 0) (void)peer_flag_wait(&ctl[rank]->ag_flag[r], seq, timeout_ticks, err, 3);
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     const double* __restrict__ src = ag[rank] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)r * m;
     double* __restrict__ dst = recv + (int64_t)r * count + off;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = sys_load(src + i);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 }  // namespace
@@ -221,10 +190,10 @@ int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
         Plan& pm = const_cast<Plan&>(p);
         const unsigned long long seq = ++pm.seq;
         const int par = (int)(seq & 1ull);
-        const unsigned gp = (unsigned)std::max<int64_t>(1, (4 * (int64_t)ns + 255) / 256);
+        const unsigned gp = (unsigned)std::max<int64_t>(1, (2 * (int64_t)ns + 255) / 256);
         hipLaunchKernelGGL(k_peer_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put + (size_t)par * nn,
                            p.d_rflag, seq, p.d_done);
-        const unsigned gu = (unsigned)std::max<int64_t>(1, (4 * (int64_t)nr + 255) / 256);
+        const unsigned gu = (unsigned)std::max<int64_t>(1, (2 * (int64_t)nr + 255) / 256);
         hipLaunchKernelGGL(k_peer_wait_unpack, dim3(gu), dim3(256), 0, s, nr, nn, p.recv_idx, p.win_recv[par], p.win_flag, seq, x,
                            pe->err_dev, pe->timeout_ticks);
         return SNS_OK;
@@ -284,8 +253,7 @@ int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t s) {
         CTRY(peer_check(c));
         for (int off = 0; off < count; off += PEER_AR_MAX) {
             const int m = std::min(PEER_AR_MAX, count - off);
-            hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, ++pe->ar_seq, pe->rank, pe->nranks,
-                               pe->d_ctl, pe->err_dev, pe->timeout_ticks);
+            hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, peer_next_allreduce(pe));
         }
         return SNS_OK;
     }
@@ -409,6 +377,11 @@ int peer_connect(Peer* p, const char* handles) {
         p->base[r] = static_cast<char*>(w);
         p->mapped[r] = true;
     }
+    return peer_finish_connect(p);
+}
+
+// device tables of the peers' control / staging areas, once base[] is complete
+int peer_finish_connect(Peer* p) {
     std::vector<PeerCtl*> ctl((size_t)p->nranks);
     std::vector<double*> ag((size_t)p->nranks);
     for (int r = 0; r < p->nranks; ++r) {
@@ -436,6 +409,17 @@ int peer_destroy(Peer* p) {
     if (p->err_host) (void)hipHostFree(p->err_host);
     delete p;
     return SNS_OK;
+}
+
+PeerArgs peer_next_allreduce(Peer* p) {
+    PeerArgs a;
+    a.seq = ++p->ar_seq;
+    a.rank = p->rank;
+    a.nranks = p->nranks;
+    a.ctl = p->d_ctl;
+    a.err = p->err_dev;
+    a.timeout_ticks = p->timeout_ticks;
+    return a;
 }
 
 int peer_check(Comm* c) {
@@ -509,6 +493,188 @@ int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t) {
     CHIP(hipMemcpy(p.d_rflag, rflag.data(), rflag.size() * sizeof(unsigned long long*), hipMemcpyHostToDevice));
     CHIP(hipMalloc((void**)&p.d_done, sizeof(unsigned int)));
     CHIP(hipMemset(p.d_done, 0, sizeof(unsigned int)));
+    return SNS_OK;
+}
+
+// ---- in-process self-test and latency probe of the protocol -------------------------------------------------------------------
+// nranks host threads of THIS process, each with its own window, stream and communicator end, wired to each other directly (one
+// address space: no IPC): a ring of halo links with `halo_nodes` nodes per direction; per collective `reps` rounds with the payload
+// checked every round, then `reps` timed rounds of the collective alone.  The streams run concurrently on the one GPU, so the figures
+// are the protocol's launch and flag costs between concurrently running queues -- everything but the xGMI hop.
+namespace {
+__global__ void k_selftest_fill(int32_t n_nodes, double base, double* __restrict__ x) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < 4 * (int64_t)n_nodes) x[t] = base + (double)t;
+}
+__global__ void k_selftest_check(int32_t n_nodes, double base, const double* __restrict__ x, int* __restrict__ bad) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < 4 * (int64_t)n_nodes && x[t] != base + (double)t) atomicAdd(bad, 1);
+}
+}  // namespace
+
+int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]) {
+    // (one HIP hardware queue per rank besides the null stream's: with the runtime's default of 4 queues a fourth rank would share one,
+    // and a kernel waiting for a flag would sit in front of the kernel that raises it)
+    if (nranks < 2 || nranks > 3 || halo_nodes < 1 || reps < 1 || !us_out) {
+        set_error("sns_peer_selftest: 2 or 3 ranks, halo_nodes >= 1, reps >= 1");
+        return SNS_E_ARG;
+    }
+    Team team(nranks);                                           // (its barrier only)
+    std::vector<Peer*> peers((size_t)nranks, nullptr);
+    std::vector<PlanOffers> offers((size_t)nranks);
+    std::vector<int> rcs((size_t)nranks, SNS_OK);
+    std::vector<std::string> errs((size_t)nranks);
+    std::vector<double> us((size_t)3 * nranks, 0.0);
+    auto work = [&](int r) {
+        auto fail = [&](int rc) { rcs[(size_t)r] = rc; errs[(size_t)r] = sns_last_error(); };
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        Comm c;
+        Plan plan;
+        double *x = nullptr, *ar = nullptr, *ags = nullptr, *agr = nullptr;
+        int* bad = nullptr;
+        char hd[64];
+        int rc = SNS_OK;
+        // every rank passes every barrier, whatever its own state: a failing rank must not strand the others
+        if (hipSetDevice(device) != hipSuccess) rc = SNS_E_HIP;
+        if (rc == SNS_OK) rc = peer_create(device, r, nranks, (size_t)32 << 20, &peers[(size_t)r], hd);
+        if (rc != SNS_OK) fail(rc);
+        team.barrier();
+        bool all_ok = true;
+        for (int q = 0; q < nranks; ++q) all_ok = all_ok && peers[(size_t)q] != nullptr;
+        if (!all_ok) return;
+        Peer* pe = peers[(size_t)r];
+        for (int q = 0; q < nranks; ++q) pe->base[q] = peers[(size_t)q]->base[q];
+        if (peer_finish_connect(pe) != SNS_OK) fail(SNS_E_HIP);
+        c.peer = pe;
+        c.rank = r;
+        c.nranks = nranks;
+        const int nn = nranks == 2 ? 1 : 2;
+        plan.nbr.assign(1, (r + 1) % nranks);
+        if (nn == 2) plan.nbr.push_back((r + nranks - 1) % nranks);
+        std::sort(plan.nbr.begin(), plan.nbr.end());
+        plan.send_ptr.assign(1, 0);
+        plan.recv_ptr.assign(1, 0);
+        for (int k = 0; k < nn; ++k) {
+            for (int i = 0; i < halo_nodes; ++i) {
+                plan.h_send_idx.push_back(i);                                    // the same owned nodes go to every neighbour
+                plan.h_recv_idx.push_back(halo_nodes * (1 + k) + i);             // ghost block k
+            }
+            plan.send_ptr.push_back((int32_t)plan.h_send_idx.size());
+            plan.recv_ptr.push_back((int32_t)plan.h_recv_idx.size());
+        }
+        const int32_t n_local = halo_nodes * (1 + nn);
+        if (rcs[(size_t)r] == SNS_OK && plan_upload(plan) != SNS_OK) fail(SNS_E_HIP);
+        if (rcs[(size_t)r] == SNS_OK && peer_plan_offer(&c, plan, offers[(size_t)r]) != SNS_OK) fail(SNS_E_COMM);
+        team.barrier();
+        for (int q = 0; q < nranks; ++q) all_ok = all_ok && rcs[(size_t)q] == SNS_OK;
+        if (!all_ok) return;
+        PlanOffers t;
+        for (int q = 0; q < nranks; ++q) t.all.insert(t.all.end(), offers[(size_t)q].mine.begin(), offers[(size_t)q].mine.end());
+        if (peer_plan_connect(&c, plan, t) != SNS_OK) fail(SNS_E_COMM);
+        const int32_t ag_count = 2048;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+            hipEventCreate(&e1) != hipSuccess || hipMalloc((void**)&x, 4 * (size_t)n_local * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&ar, 8 * sizeof(double)) != hipSuccess || hipMalloc((void**)&ags, ag_count * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&agr, (size_t)ag_count * nranks * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&bad, sizeof(int)) != hipSuccess || hipMemset(bad, 0, sizeof(int)) != hipSuccess ||
+            hipMemset(x, 0, 4 * (size_t)n_local * sizeof(double)) != hipSuccess)
+            fail(SNS_E_HIP);
+        team.barrier();
+        for (int q = 0; q < nranks; ++q) all_ok = all_ok && rcs[(size_t)q] == SNS_OK;
+        if (all_ok) {
+            const unsigned gh = (unsigned)((4 * (int64_t)halo_nodes + 255) / 256);
+            int hbad = 0;
+            const bool verbose = std::getenv("SNS_PEER_SELFTEST_VERBOSE") != nullptr;
+            bool go_on = true;
+            for (int phase = 0; phase < 3 && go_on; ++phase) {
+                if (verbose) { std::fprintf(stderr, "[peer selftest] rank %d: phase %d starts\n", r, phase); std::fflush(stderr); }
+                const int n_it = 5 + reps;
+                for (int it = 0; it < n_it && rcs[(size_t)r] == SNS_OK; ++it) {
+                    const double tag = 1.0e6 * (it + 1);
+                    int rc2 = SNS_OK;
+                    if (phase == 0) {
+                        // owned values = f(rank, round); after the exchange ghost block k must hold f(neighbour k, round)
+                        hipLaunchKernelGGL(k_selftest_fill, dim3(gh), dim3(256), 0, st, halo_nodes, tag + 1.0e3 * r, x);
+                        rc2 = comm_exchange(&c, plan, x, st);
+                        for (int k = 0; k < nn; ++k)
+                            hipLaunchKernelGGL(k_selftest_check, dim3(gh), dim3(256), 0, st, halo_nodes, tag + 1.0e3 * plan.nbr[(size_t)k],
+                                               x + 4 * (size_t)halo_nodes * (1 + k), bad);
+                    } else if (phase == 1) {
+                        hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(256), 0, st, 1, tag + (double)r, ar);      // 4 values
+                        rc2 = comm_allreduce_sum(&c, ar, 4, st);
+                        // sum over ranks of (tag + r + t) = nranks (tag + t) + nranks (nranks - 1) / 2
+                        double expect[4], got[4];
+                        if (it == n_it - 1) {
+                            (void)hipMemcpyAsync(got, ar, sizeof(got), hipMemcpyDeviceToHost, st);
+                            (void)hipStreamSynchronize(st);
+                            for (int q = 0; q < 4; ++q) {
+                                expect[q] = 0.0;
+                                for (int rr = 0; rr < nranks; ++rr) expect[q] += tag + (double)rr + (double)q;
+                                if (got[q] != expect[q]) ++hbad;
+                            }
+                        }
+                    } else {
+                        hipLaunchKernelGGL(k_selftest_fill, dim3((ag_count + 255) / 256), dim3(256), 0, st, ag_count / 4, tag + 1.0e3 * r, ags);
+                        rc2 = comm_allgather(&c, ags, agr, ag_count, st);
+                        for (int rr = 0; rr < nranks; ++rr)
+                            hipLaunchKernelGGL(k_selftest_check, dim3((ag_count + 255) / 256), dim3(256), 0, st, ag_count / 4,
+                                               tag + 1.0e3 * rr, agr + (size_t)rr * ag_count, bad);
+                    }
+                    if (rc2 != SNS_OK) fail(rc2);
+                }
+                // ... and the same number of rounds of the collective alone, timed
+                team.barrier();
+                (void)hipEventRecord(e0, st);
+                for (int it = 0; it < reps && rcs[(size_t)r] == SNS_OK; ++it) {
+                    const int rc2 = phase == 0 ? comm_exchange(&c, plan, x, st)
+                                  : phase == 1 ? comm_allreduce_sum(&c, ar, 4, st) : comm_allgather(&c, ags, agr, ag_count, st);
+                    if (rc2 != SNS_OK) fail(rc2);
+                }
+                (void)hipEventRecord(e1, st);
+                (void)hipStreamSynchronize(st);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                us[(size_t)3 * r + phase] = 1.0e3 * ms / reps;
+                if (rcs[(size_t)r] == SNS_OK && peer_check(&c) != SNS_OK) fail(SNS_E_COMM);
+                if (verbose) {
+                    std::fprintf(stderr, "[peer selftest] rank %d: phase %d done, rc %d, %.1f us per round\n", r, phase, rcs[(size_t)r],
+                                 us[(size_t)3 * r + phase]);
+                    std::fflush(stderr);
+                }
+                // all ranks leave the phase loop together: the verdicts are read between two barriers, while nobody writes one
+                team.barrier();
+                for (int q = 0; q < nranks; ++q) go_on = go_on && rcs[(size_t)q] == SNS_OK;
+                team.barrier();
+            }
+            (void)hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost);
+            int dbad = hbad;
+            if (dbad != 0 && rcs[(size_t)r] == SNS_OK) {
+                set_error("peer self-test: rank " + std::to_string(r) + " received " + std::to_string(dbad) + " wrong values");
+                fail(SNS_E_COMM);
+            }
+        }
+        team.barrier();                                              // nobody frees a window a peer may still store into
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        plan_free(plan);
+        (void)hipFree(x); (void)hipFree(ar); (void)hipFree(ags); (void)hipFree(agr); (void)hipFree(bad);
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < nranks; ++r) th.emplace_back(work, r);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < nranks; ++r)
+        if (peers[(size_t)r]) (void)peer_destroy(peers[(size_t)r]);
+    for (int r = 0; r < nranks; ++r)
+        if (rcs[(size_t)r] != SNS_OK) {
+            set_error(errs[(size_t)r]);
+            return rcs[(size_t)r];
+        }
+    for (int k = 0; k < 3; ++k) {
+        us_out[k] = 0.0;
+        for (int r = 0; r < nranks; ++r) us_out[k] = std::max(us_out[k], us[(size_t)3 * r + k]);
+    }
     return SNS_OK;
 }
 

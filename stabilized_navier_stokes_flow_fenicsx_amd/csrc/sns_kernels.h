@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "sns.h"
+#include "sns_peer_dev.h"
 
 namespace sns {
 
@@ -75,6 +76,8 @@ __global__ void k_reduce_final(int nblocks, int nred, const double* partial, dou
 __global__ void k_reduce_chunks(int nblocks, int nred, const double* partial, double* out);
 template <int WHICH>
 __global__ void k_reduce_final_bicg(int nblocks, const double* partial, double* red_out, double* sc);
+template <int WHICH>
+__global__ void k_reduce_final_bicg_peer(int nblocks, const double* partial, double* red_out, double* sc, PeerArgs pa);
 __global__ void k_dot2(int64_t n, const double* x, const double* y, double* partial);
 __global__ void k_axpby(int64_t n, double a, const double* x, double b, double* y);
 __global__ void k_axpbypcz(int64_t n, double a, const double* x, double b, const double* y, double c, double* z);

@@ -2180,6 +2180,43 @@ __global__ __launch_bounds__(256) void k_reduce_final_bicg(int nblocks, const do
 template __global__ void k_reduce_final_bicg<1>(int, const double*, double*, double*);
 template __global__ void k_reduce_final_bicg<2>(int, const double*, double*, double*);
 
+// The same launch for a partitioned run over the peer-window transport: local final stage, all-reduce over the ranks (stores
+// into the peers' windows, sns_peer_dev.h), scalar update -- where RCCL needs k_reduce_final + ncclAllReduce + k_bicg_alpha.
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_reduce_final_bicg_peer(int nblocks, const double* __restrict__ partial,
+                                                                double* __restrict__ red_out, double* __restrict__ sc,
+                                                                PeerArgs pa) {
+    constexpr int NRED = WHICH == 1 ? 1 : 5;
+    __shared__ double red[NRED][256];
+    __shared__ double tot[8];
+    double s[NRED];
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) s[k] += partial[(int64_t)b * NRED + k];
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < NRED) tot[threadIdx.x] = red[threadIdx.x][0];
+    __syncthreads();
+    peer_allreduce_block(tot, NRED, pa);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) red_out[k] = tot[k];
+        if (WHICH == 1) bicg_alpha_update(sc, tot);
+        else bicg_omega_update(sc, tot);
+    }
+}
+template __global__ void k_reduce_final_bicg_peer<1>(int, const double*, double*, double*, PeerArgs);
+template __global__ void k_reduce_final_bicg_peer<2>(int, const double*, double*, double*, PeerArgs);
+
 // first stage of a long reduction: block (c, k) sums partial[b][k] over the 2048 blocks b of chunk c (fixed order)
 __global__ __launch_bounds__(256) void k_reduce_chunks(int nblocks, int nred, const double* __restrict__ partial,
                                                        double* __restrict__ out) {

@@ -373,6 +373,17 @@ class FlowProblem:
         return ms.value
 
 
+def _bench_collective(self, which: str, count: int = 5, reps: int = 200) -> float:
+    """ms per collective of the attached communicator, back to back (collective call; measurement hook)."""
+    ms = C.c_double()
+    check(self.lib.sns_bench_collective(self.h, {"exchange": 0, "allreduce": 1, "allgather": 2}[which], int(count), int(reps),
+                                        C.byref(ms)))
+    return ms.value
+
+
+FlowProblem.bench_collective = _bench_collective
+
+
 class PeerGroup:
     """Peer-window communicator of the C-ABI (sns_peer_*): one process per GPU of one node, the collectives of the solver are
     stores into the other ranks' IPC-mapped windows -- no RCCL in the data path.  The 64-byte IPC handles are exchanged through

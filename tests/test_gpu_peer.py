@@ -100,3 +100,22 @@ def test_a_rank_that_never_arrives_is_an_error_not_a_hang(tmp_path):
     for r in waited:
         assert not r["ok"] and "peer transport" in r.get("sns_error", "") and "gave up waiting" in r["sns_error"], r
         assert r["seconds"] < 60.0
+
+
+@pytest.mark.parametrize("nranks,halo_nodes", [(2, 5776), (3, 64), (3, 5776)])
+def test_protocol_selftest_between_concurrent_queues(nranks, halo_nodes):
+    """sns_peer_selftest: the put / flag / wait protocol between nranks concurrently running HIP queues of one process (a ring of
+    halo links; 5776 nodes = the 76 x 76 interface of the 10 M-tet duct's x-slabs), every payload of every round verified --
+    including the double-buffered receive buffers and slot tables over 200 rounds -- then 200 timed rounds of each collective alone
+    (printed).  (Ranks = threads here: at most 3, one hardware queue each; the process tests above have no such limit.)"""
+    import ctypes as C
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    lib = _lib.load()
+    us = (C.c_double * 3)()
+    rc = lib.sns_peer_selftest(0, nranks, halo_nodes, 200, us)
+    assert rc == 0, lib.sns_last_error().decode()
+    print(f"  {nranks} ranks, {halo_nodes} halo nodes ({32 * halo_nodes / 1e3:.0f} kB) per link: exchange {us[0]:.1f} us, all-reduce {us[1]:.1f} us, "
+          f"all-gather {us[2]:.1f} us per round")
+    assert 0.0 < us[0] < 5000.0 and 0.0 < us[1] < 5000.0 and 0.0 < us[2] < 5000.0
