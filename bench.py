@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--weak-timeout", type=float, default=300.0,
                     help="N>1: seconds the weak-scaling leg may take; after that the line is printed with "
                          "weak_scaling = {error: timeout} and every rank exits 0 (the headline is never lost to it)")
+    ap.add_argument("--no-peer", action="store_true",
+                    help="N>1: skip the repetition of the timed steps over the peer-window transport (sns_peer_*)")
+    ap.add_argument("--peer-timeout", type=float, default=300.0,
+                    help="N>1: seconds the peer-transport leg may take (as --weak-timeout: the measured line is never lost to it)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="extra sns_options field for experiments, e.g. --opt amg_agg_size=4")
     ap.add_argument("--strong", action="store_true", help="(default since round 2; kept for old command lines)")
@@ -163,8 +167,9 @@ class Watchdog:
 WATCHDOG = None
 
 
-def run_weak_leg_guarded(out, rank, seconds, leg):
-    """The weak-scaling leg must never cost the already-measured headline: `leg()` (which fills out["weak_scaling"]) runs
+def run_weak_leg_guarded(out, rank, seconds, leg, key="weak_scaling", what="weak-scaling"):
+    """The weak-scaling leg (and, with key = "peer_transport", the peer-transport leg) must never cost the already-measured
+    headline: `leg()` (which fills out[key]) runs
     in this thread under a deadline kept by a timer thread of this same process (no child, no re-exec).  If the leg has
     not returned after `seconds`, rank 0 prints THE line with weak_scaling = {"error": "timeout ..."} and every rank leaves
     with os._exit(0) -- no clean-up that could wait on a stuck collective; the ranks enter the leg behind a common barrier, so
@@ -178,10 +183,9 @@ def run_weak_leg_guarded(out, rank, seconds, leg):
                 return
             state["over"] = True
             if rank == 0:
-                out["weak_scaling"] = {"error": f"timeout: the weak-scaling leg did not finish within {seconds:.0f} s "
-                                                "(headline unaffected)"}
+                out[key] = {"error": f"timeout: the {what} leg did not finish within {seconds:.0f} s (headline unaffected)"}
                 print(json.dumps(out), flush=True)
-            print(f"[bench] rank {rank}: weak-scaling leg exceeded {seconds:.0f} s: leaving with the headline only",
+            print(f"[bench] rank {rank}: {what} leg exceeded {seconds:.0f} s: leaving with the headline only",
                   file=sys.stderr, flush=True)
             os._exit(0)
 
@@ -351,7 +355,7 @@ def host_problem(cfg, cells, length, inlet="image"):
             f"two-stream channel 4x1x1, {cells[0]}x{cells[1]}x{cells[2]} cells, analytic inlet profiles, flowrate ratio 0.5")
 
 
-def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on, inlet="image"):
+def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on, inlet="image", group=None):
     """(P, n_dof_global, n_tets_global, description, host_inputs) of one BASELINE config on this rank.
     Config 5 (duct): x-slab element partition, every rank meshes only its own slab (partition.duct_slab_part).
     Configs 3 / 4 / 4u: the global mesh is built on every rank and RCB-partitioned (setup cost, not timed)."""
@@ -362,7 +366,7 @@ def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on
     if cfg == "5":
         if dist_on:
             part = PT.duct_slab_part(cells, length, rank, world)
-            P = FlowProblem.from_part(part, device=dev, **opts)
+            P = FlowProblem.from_part(part, device=dev, group=group, **opts)
         else:
             mesh = M.duct_mesh(cells, length)
             bcs = B.duct_bcs(mesh).flatten()
@@ -373,7 +377,8 @@ def build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on
         desc = f"duct [0,{length:g}]x[-.5,.5]^2, {cells[0]}x{cells[1]}x{cells[2]} cells"
     else:
         mesh, bcs, desc = host_problem(cfg, cells, length, inlet)
-        P = FlowProblem.distributed(mesh, bcs, device=dev, **opts) if dist_on else FlowProblem(mesh, bcs, device=dev, **opts)
+        P = (FlowProblem.distributed(mesh, bcs, device=dev, group=group, **opts) if dist_on
+             else FlowProblem(mesh, bcs, device=dev, **opts))
         host = (mesh, bcs)
         nd, nt = mesh.num_dofs, mesh.num_tets
     return P, nd, nt, desc, host
@@ -682,6 +687,7 @@ def main():
                    "amg_levels": tm.amg_levels, "stokes_its": sres.its},
         "roofline": roofline,
         "all_f64_preconditioner": all_f64,
+        "peer_transport": None,
         "weak_scaling": None,
         "cpu_baseline": None,
     }
@@ -690,8 +696,49 @@ def main():
     del P, U, w
     torch.cuda.empty_cache()
 
-    # ---- second key for N > 1: the weak layout (every GPU keeps the single-GPU share) --------------------------
+    # ---- N > 1: the same timed steps once more over the peer-window transport --------------------------------------
+    # (sns_peer_*: halo exchange / all-reduce / all-gather as stores into the other ranks' IPC-mapped windows, no RCCL in the
+    # data path -- made for the latency-bound strong split.  Same W + K steps, same barriers, same clock.  The line's `value`
+    # is the faster of the two transports, named in `transport`; both figures stay on the line.  The leg runs under a deadline
+    # like the weak leg and every device-side wait inside it is bounded: a transport problem costs this key, not the line.)
     WATCHDOG.tick("headline done")
+    if dist_on and not args.no_peer:
+        def peer_leg():
+            peers = None
+            try:
+                from stabilized_navier_stokes_flow_fenicsx_amd.solver import PeerGroup
+                peers = PeerGroup(device=f"cuda:{local_rank}")
+                Pp, _, _, _, _ = build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, True, args.inlet, group=peers)
+                Up, sp = Pp.stokes_solve()
+                if sp.reason > 0:
+                    ms_p, log_p, _ = timed_newton_steps(Pp, Up, args.steps, args.warmup, world)
+                    tmp, cp = Pp.timings(), Pp.counters()
+                    out["peer_transport"] = {
+                        "value": round(n_dof_global / (ms_p * 1e-3) / 1e6, 3), "unit": "M-DOF/s", "ms_per_step": round(ms_p, 3),
+                        "transport": Pp.comm_info()["transport"], "ksp_its": [b for _, b, _ in log_p], "stokes_its": sp.its,
+                        "phase_ms_per_step": {"assemble": round(tmp.assemble_ms / args.steps, 3),
+                                              "pc_setup": round(tmp.pc_setup_ms / args.steps, 3),
+                                              "krylov": round(tmp.krylov_ms / args.steps, 3)},
+                        "krylov_loop_last_solve": {"allreduces": cp["allreduces"], "halo_exchanges": cp["exchanges"]}}
+                else:
+                    out["peer_transport"] = {"error": f"Stokes solve reason {sp.reason}"}
+                Pp.close()
+                peers.close()
+            except Exception as exc:          # noqa: BLE001 -- reported in the line
+                out["peer_transport"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+        run_weak_leg_guarded(out, rank, args.peer_timeout, peer_leg, key="peer_transport", what="peer-transport")
+        pt = out.get("peer_transport") or {}
+        # every rank measured the same MAX-over-ranks time, so every rank takes the same decision
+        if world > 1 and "value" in pt and pt["value"] > out["value"] and pt["ksp_its"] and all(k > 0 for k in pt["ksp_its"]):
+            out["rccl_transport"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "unit": "M-DOF/s"}
+            out["value"], out["ms_per_step"], out["transport"] = pt["value"], pt["ms_per_step"], pt["transport"]
+            out["config"]["transport_note"] = ("value / ms_per_step: the peer-window leg (the faster transport; its phases and counters "
+                                               "under peer_transport); roofline, phase_ms_per_step and counters in config: the RCCL leg "
+                                               "(its figure under rccl_transport)")
+
+    # ---- second key for N > 1: the weak layout (every GPU keeps the single-GPU share) --------------------------
+    WATCHDOG.tick("peer leg done")
     if cfg == "5" and dist_on and not args.no_weak:
         sc = float(world) ** (1.0 / 3.0)
         wcells = tuple(int(round(c * sc)) for c in cells)
