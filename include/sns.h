@@ -165,7 +165,8 @@ typedef struct {
                                of the 4 x 4 nodal block: x <- x + w B^-1 (b - A x), one launch per sweep like before and worth about
                                two point-block sweeps, so the levels run the shorter schedule below (csrc/sns_block.hip).  The inverse
                                blocks are held in the format of the level's matrix copy (fp16 + one fp32 scale per row by default,
-                               2 KiB + 128 B per aggregate; fp32 with amg_f32_matrix = 1).  2: the fine level as well.  0: nodal blocks everywhere (rounds 1-3).
+                               2 KiB + 128 B per aggregate; fp32 with amg_f32_matrix = 1).  2: the fine level as well (1 takes it on partitioned handles only, see
+                               amg_block_fine_rows).  0: nodal blocks everywhere (rounds 1-3).
                                Needs amg_f32_matrix != 0 and amg_agg_size <= 8; levels where it does not apply keep the nodal
                                blocks and their sweep counts.  Fixed when the hierarchy is built */
     int    amg_bnu_l1;      /* sweeps after the coarse-grid correction on level 1 under amg_block_smooth (3; one sweep before it);
@@ -189,6 +190,13 @@ typedef struct {
                                inverse blocks were fp32 -- 4 KiB per aggregate -- a block sweep cost 1.5x a nodal sweep on a large
                                level and the limit was 8192; in the format of the level's fp16 matrix copy, 2 KiB + row scales, it
                                costs 1.2x and every coarse level gains: 10 M-tet duct 137.5 -> 127-130 ms per Newton iteration) */
+    int    amg_block_fine_rows; /* under amg_block_smooth = 1: aggregate blocks on the FINE level too on a PARTITIONED handle (>= 2 ranks)
+                               whose fine level has at most this many rows per rank (600000; 0 = never).  The strong split is
+                               latency-bound: 15-21 % fewer BiCGStab iterations -- and collectives -- for 6 % more time per
+                               iteration (10 M-tet duct on 2 / 4 / 8 ranks: 41 / 43 / 47 -> 35 / 33 / 36 iterations; its 1/8 share on
+                               one GPU 19.3-20.2 -> 17.9-18.0 ms per Newton iteration), where a whole mesh on one GPU loses
+                               (10 M tets: 42 -> 37 iterations, 129 -> 132 ms; 893 k nodes +2.5 %), which is why a single-GPU
+                               handle takes them with amg_block_smooth = 2 only.  Fixed when the hierarchy is built */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

@@ -48,6 +48,7 @@ class SnsOptions(C.Structure):
         ("amg_ritz_limit", C.c_int),
         ("amg_growth_check", C.c_int),
         ("amg_block_max_rows", C.c_int),
+        ("amg_block_fine_rows", C.c_int),
     ]
 
 

@@ -575,10 +575,20 @@ int append_level(sns_ctx* h, const HostPattern& P, int32_t n_owned, bool with_xg
 
 // Aggregate-block Jacobi smoother (amg_block_smooth, csrc/sns_block.hip), symbolic part: the member rows of every aggregate of
 // level L padded to 8 slots.  Levels whose aggregates can have more than 8 members (amg_agg_size > 8) keep the nodal blocks.
+// Aggregate blocks on the FINE level: always with amg_block_smooth = 2; with 1 on a partitioned handle whose share of the fine level is
+// at most amg_block_fine_rows rows per rank -- the latency-bound strong split, where 20 % fewer iterations (and collectives) outweigh
+// the inverse blocks' bytes.  Global counts only: every rank answers alike.
+inline bool fine_blocks_wanted(const sns_ctx* h) {
+    if (h->opt.amg_block_smooth >= 2) return true;
+    if (h->opt.amg_block_smooth < 1 || h->opt.amg_block_fine_rows <= 0) return false;
+    const Comm* c = h->comm.get();
+    if (!c || !c->active() || c->nranks < 2 || h->n_global_fine <= 0) return false;
+    return h->n_global_fine <= (int64_t)h->opt.amg_block_fine_rows * c->nranks;
+}
 int upload_block_rows(sns_ctx* h, int l, Level& L, const std::vector<int32_t>& m_ptr, const std::vector<int32_t>& m_idx,
                       int32_t nc_owned) {
     const int mode = h->opt.amg_block_smooth;
-    if (mode <= 0 || (l == 0 && mode < 2) || nc_owned < 0) return SNS_OK;
+    if (mode <= 0 || (l == 0 && !fine_blocks_wanted(h)) || nc_owned < 0) return SNS_OK;
     // blocks = aggregates; an aggregate of more than 8 nodes (a leftover node joined a full neighbour) is split in member order
     std::vector<int32_t> rows, of((size_t)std::max(1, L.n), -1);
     rows.reserve((size_t)8 * std::max(1, nc_owned));
@@ -606,7 +616,7 @@ inline bool block_active(const sns_ctx* h, int l) {
     if (l < 0 || l + 1 >= (int)h->levels.size()) return false;                 // the coarsest level is solved or point-smoothed
     const Level& L = h->levels[l];
     if (!L.blk_rows) return false;
-    if (l == 0 && (h->opt.amg_block_smooth < 2 || L.xg)) return false;
+    if (l == 0 && !fine_blocks_wanted(h)) return false;
     if (h->rep_level > 0 && l == h->rep_level - 1) return false;               // only the source of the replicated copy
     // latency-bound levels only (rows per rank, the same figure on every rank)
     const bool replicated = h->rep_level > 0 && l >= h->rep_level;
@@ -1223,7 +1233,7 @@ inline int level_nu(const sns_ctx* h, int l) {
 // sweep; with several sweeps the ghost values would be frozen while the owned ones move, which measurably hurts
 // the Stokes operator (8 slabs of the 10 M-tet duct: 47 -> 65 iterations) -- so only where nu = 1 (the fine level)
 inline bool level_px(const sns_ctx* h, int l, const Level& L) {
-    return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1 && !block_active(h, l);
+    return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1 && (l == 0 || !block_active(h, l));
 }
 inline bool uses_ghosts_in_sweeps(const sns_ctx* h, int l, const Level& L) { return level_sx(h, L) || level_px(h, l, L); }
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
@@ -1701,7 +1711,7 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_nu_scale_with_size);
     sig.push_back(h->opt.amg_fine_cycle);
     sig.push_back(h->opt.amg_block_smooth); sig.push_back(h->opt.amg_bnu_l1); sig.push_back(h->opt.amg_bnu_l2);
-    sig.push_back(h->opt.amg_bnu_deep); sig.push_back(h->opt.amg_block_max_rows);
+    sig.push_back(h->opt.amg_bnu_deep); sig.push_back(h->opt.amg_block_max_rows); sig.push_back(h->opt.amg_block_fine_rows);
     sig.push_back(restrict_fuses_first(h, gl - 1) ? 1.0 : 0.0);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
@@ -2507,6 +2517,7 @@ void sns_default_options(sns_options* o) {
     o->amg_ritz_limit = 1;
     o->amg_growth_check = 1;
     o->amg_block_max_rows = 0;
+    o->amg_block_fine_rows = 600000;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
