@@ -490,17 +490,21 @@ int host_allgather(sns_ctx* h, const std::vector<double>& mine, std::vector<doub
     Comm* c = h->comm.get();
     const size_t len = mine.size();
     double *ds = nullptr, *dr = nullptr;
-    SNS_TRY(dev_alloc(&ds, std::max<size_t>(1, len)));
-    SNS_TRY(dev_alloc(&dr, std::max<size_t>(1, len * c->nranks)));
-    HIP_TRY(hipMemcpy(ds, mine.data(), len * sizeof(double), hipMemcpyHostToDevice));
-    SNS_TRY(comm_allgather(c, ds, dr, (int)len, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    SNS_TRY(peer_check(c));
-    all.resize(len * c->nranks);
-    HIP_TRY(hipMemcpy(all.data(), dr, all.size() * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(ds);
-    (void)hipFree(dr);
-    return SNS_OK;
+    auto body = [&]() -> int {
+        SNS_TRY(dev_alloc(&ds, std::max<size_t>(1, len)));
+        SNS_TRY(dev_alloc(&dr, std::max<size_t>(1, len * c->nranks)));
+        HIP_TRY(hipMemcpy(ds, mine.data(), len * sizeof(double), hipMemcpyHostToDevice));
+        SNS_TRY(comm_allgather(c, ds, dr, (int)len, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        SNS_TRY(peer_check(c));
+        all.resize(len * c->nranks);
+        HIP_TRY(hipMemcpy(all.data(), dr, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+        return SNS_OK;
+    };
+    const int rc = body();
+    if (ds) (void)hipFree(ds);
+    if (dr) (void)hipFree(dr);
+    return rc;
 }
 
 // Every link of a halo plan must be posted by BOTH ends with matching counts -- rank a sends s nodes to b <=> b receives s nodes

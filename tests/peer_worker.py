@@ -75,7 +75,7 @@ def main():
                            newton_its=n.its, newton_reason=n.reason, ksp_its=list(n.ksp_its) if hasattr(n.ksp_its, "__iter__") else n.ksp_its,
                            serial=dict(stokes_its=rs.its, newton_its=ns.its, newton_reason=ns.reason),
                            err_stokes=rel(Ug, Us), err_newton=rel(wg, ws), err_spmv=rel(yg, ys),
-                           levels=P.timings().amg_levels, exchanges=c.get("exchanges"), allreduces=c.get("allreduces"),
+                           levels=P.timings().amg_levels, cycle=[(x["kind"], x["pre"], x["post"]) for x in P.cycle()], exchanges=c.get("exchanges"), allreduces=c.get("allreduces"),
                            n_owned=int(part.n_owned), neighbors=[int(v) for v in part.neighbors], seconds=time.time() - t0)
             except SnsError as e:
                 out.update(ok=False, sns_error=str(e), seconds=time.time() - t0)

@@ -86,6 +86,8 @@ def test_partitioned_solve_between_processes_over_peer_windows(kind, world, tmp_
         assert r["stokes_reason"] > 0 and r["newton_reason"] == r["serial"]["newton_reason"] and r["newton_its"] == r["serial"]["newton_its"]
         assert (r["stokes_its"], r["ksp_its"], r["levels"]) == (r0["stokes_its"], r0["ksp_its"], r0["levels"])   # same decisions everywhere
         assert r["stokes_its"] <= 2 * r["serial"]["stokes_its"] + 4
+    # a partitioned handle with few fine rows per rank smooths its FINE level with the aggregate blocks too (amg_block_fine_rows)
+    assert all(r["cycle"][0][0] == 1 for r in res), r0["cycle"]
     if kind == "duct-rep-dense":
         assert r0["levels"] == 2                               # fine level + the replicated, directly solved level 1
     if kind == "cavity":
