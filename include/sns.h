@@ -287,7 +287,8 @@ int sns_peer_destroy(void* peer);
 /* Self-test and latency probe of the protocol inside ONE process: nranks (2 or 3) threads with a window, a stream and a
  * communicator end each, wired directly (no IPC), a ring of halo links of `halo_nodes` nodes per direction.  Per collective -- halo
  * exchange, all-reduce (4 doubles), all-gather (2048 doubles per rank) -- `reps` rounds with every payload verified, then `reps`
- * timed rounds of the collective alone: us_out = microseconds per round (max over ranks).  SNS_E_COMM on a wrong value or a timeout. */
+ * timed rounds of the collective alone: us_out = microseconds per round (max over ranks); then three verified rounds of the long forms
+ * (an all-reduce of 40 doubles = two launches, an all-gather of more than three staging chunks).  SNS_E_COMM on a wrong value or a timeout. */
 int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
 int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
                     const int32_t* send_ptr, const int32_t* send_idx,

@@ -647,8 +647,47 @@ int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_ou
                 for (int q = 0; q < nranks; ++q) go_on = go_on && rcs[(size_t)q] == SNS_OK;
                 team.barrier();
             }
-            (void)hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost);
-            int dbad = hbad;
+            // the long forms, three verified rounds each: an all-reduce of 40 doubles (two launches of <= PEER_AR_MAX) and an
+            // all-gather of more than three staging chunks with a ragged last one
+            if (go_on) {
+                const int64_t per = (int64_t)(pe->ag_doubles / (size_t)nranks);
+                const int64_t big = 3 * per + 1000;
+                double *ar40 = nullptr, *bs = nullptr, *br = nullptr;
+                if (hipMalloc((void**)&ar40, 40 * sizeof(double)) != hipSuccess || hipMalloc((void**)&bs, (size_t)big * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&br, (size_t)big * nranks * sizeof(double)) != hipSuccess)
+                    fail(SNS_E_HIP);
+                team.barrier();
+                bool ok2 = true;
+                for (int q = 0; q < nranks; ++q) ok2 = ok2 && rcs[(size_t)q] == SNS_OK;
+                team.barrier();
+                for (int it = 0; it < 3 && ok2 && rcs[(size_t)r] == SNS_OK; ++it) {
+                    const double tag = 7.0e6 * (it + 1);
+                    hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(256), 0, st, 10, tag + (double)r, ar40);              // 40 values
+                    int rc2 = comm_allreduce_sum(&c, ar40, 40, st);
+                    double got[40];
+                    (void)hipMemcpyAsync(got, ar40, sizeof(got), hipMemcpyDeviceToHost, st);
+                    (void)hipStreamSynchronize(st);
+                    for (int q = 0; q < 40; ++q) {
+                        double expect = 0.0;
+                        for (int rr = 0; rr < nranks; ++rr) expect += tag + (double)rr + (double)q;
+                        if (got[q] != expect) ++hbad;
+                    }
+                    const unsigned gbig = (unsigned)((big + 255) / 256);
+                    hipLaunchKernelGGL(k_selftest_fill, dim3(gbig), dim3(256), 0, st, (int32_t)(big / 4), tag + 1.0e3 * r, bs);
+                    if (rc2 == SNS_OK) rc2 = comm_allgather(&c, bs, br, (int)(big / 4 * 4), st);
+                    for (int rr = 0; rr < nranks; ++rr)
+                        hipLaunchKernelGGL(k_selftest_check, dim3(gbig), dim3(256), 0, st, (int32_t)(big / 4), tag + 1.0e3 * rr,
+                                           br + (size_t)rr * (size_t)(big / 4 * 4), bad);
+                    (void)hipStreamSynchronize(st);
+                    if (rc2 != SNS_OK) fail(rc2);
+                    else if (peer_check(&c) != SNS_OK) fail(SNS_E_COMM);
+                }
+                team.barrier();                                          // (buffers of the round are read by nobody else: local frees)
+                (void)hipFree(ar40); (void)hipFree(bs); (void)hipFree(br);
+            }
+            int dbad = 0;
+            (void)hipMemcpy(&dbad, bad, sizeof(int), hipMemcpyDeviceToHost);
+            dbad += hbad;
             if (dbad != 0 && rcs[(size_t)r] == SNS_OK) {
                 set_error("peer self-test: rank " + std::to_string(r) + " received " + std::to_string(dbad) + " wrong values");
                 fail(SNS_E_COMM);
