@@ -59,6 +59,13 @@ def parse_args(argv=None):
     ap.add_argument("--weak-timeout", type=float, default=300.0,
                     help="N>1: seconds the weak-scaling leg may take; after that the line is printed with "
                          "weak_scaling = {error: timeout} and every rank exits 0 (the headline is never lost to it)")
+    ap.add_argument("--transport", type=str, default="rccl", choices=["rccl", "peer"],
+                    help="N>1: communicator of the HEADLINE run: rccl (default; the peer-window transport then runs as a second, "
+                         "guarded leg) or peer (sns_peer_*: no RCCL in the data path; no second leg)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="REHEARSAL of --gpus N on a 1-GPU box: every rank uses cuda:0 and torch.distributed runs on gloo; needs "
+                         "--transport peer (RCCL cannot put two ranks on one GPU).  The ranks compete for the one GPU: the line is "
+                         "marked shared_gpu_rehearsal and its timings mean nothing")
     ap.add_argument("--no-peer", action="store_true",
                     help="N>1: skip the repetition of the timed steps over the peer-window transport (sns_peer_*)")
     ap.add_argument("--peer-timeout", type=float, default=300.0,
@@ -441,6 +448,18 @@ def dry_run(args, cfg, cells, length, world, rank):
     return 0 if ok else 4
 
 
+def _dist_allreduce(t, op=None):
+    """all_reduce of a small device tensor on whatever backend carries torch.distributed here (gloo: through the host)"""
+    import torch.distributed as dist
+    kw = {} if op is None else {"op": op}
+    if dist.get_backend() == "gloo":
+        tc = t.cpu()
+        dist.all_reduce(tc, **kw)
+        t.copy_(tc)
+    else:
+        dist.all_reduce(t, **kw)
+
+
 def halo_overlap_selfcheck(P, world):
     """First contact of the overlapped halo path with a real multi-rank RCCL communicator: one operator pass with the
     interior / boundary split on two streams against the same pass as exchange-then-full-pass (halo_overlap = 0).
@@ -459,7 +478,7 @@ def halo_overlap_selfcheck(P, world):
     y1 = P.spmv(x.clone())[:no].clone()
     bad = torch.tensor([0.0 if torch.equal(y0, y1) else 1.0], dtype=torch.float64, device=P.device)
     if world > 1:
-        dist.all_reduce(bad)
+        _dist_allreduce(bad)
     if float(bad) > 0:
         P.set_options(halo_overlap=0)
         return f"MISMATCH on {int(bad)} rank(s): overlapped halo disabled, exchange-then-full-pass used"
@@ -508,7 +527,7 @@ def timed_newton_steps(P, U, steps, warmup, world):
     P.time_kernels(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _dist_allreduce(t, dist.ReduceOp.MAX)
         dt = float(t)
     return dt / max(1, steps) * 1e3, log, state["w"]
 
@@ -533,15 +552,27 @@ def main():
     length = args.length
     if args.dry_run:
         return dry_run(args, cfg, cells, length, world, rank)
+    if args.shared_gpu:
+        if args.transport != "peer":
+            print("error: --shared-gpu needs --transport peer (RCCL cannot put two ranks on one GPU)", file=sys.stderr)
+            return 2
+        local_rank = 0                                           # every rank on the box's one GPU (rehearsal)
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get("SNS_FORCE_DIST"))          # rehearse the partitioned path with one rank
     dist_on = world > 1 or force_dist
+    peers = None
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29561")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.transport == "peer":
+            from stabilized_navier_stokes_flow_fenicsx_amd.solver import PeerGroup
+            peers = PeerGroup(device=f"cuda:{local_rank}")
 
     Re = args.re if args.re is not None else {"5": 200.0, "4": 50.0, "4u": 50.0, "3": 100.0}[cfg]
     opts = dict(reynolds=Re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
@@ -551,10 +582,10 @@ def main():
 
     # ---- headline: the SAME mesh on N GPUs (strong scaling; N = 1 is the mesh on one GPU) ----------------------
     P, n_dof_global, n_tets_global, desc, host = build_problem(cfg, cells, length, Re, world, rank, local_rank, opts, dist_on,
-                                                               args.inlet)
+                                                               args.inlet, group=peers)
     WATCHDOG.tick("setup")
     comm = P.comm_info()
-    if dist_on and world > 1 and comm["rccl_ranks"] != world:
+    if dist_on and world > 1 and peers is None and comm["rccl_ranks"] != world:
         print(f"error: RCCL communicator has {comm['rccl_ranks']} ranks, expected {world}", file=sys.stderr)
         return 5
     U, sres = P.stokes_solve()                       # initial guess, as the reference does (:519-523)
@@ -664,6 +695,8 @@ def main():
         # true = this number comes from the fallback launch (exchange-then-full-pass) after the production two-stream path
         # FAILED on this machine: a defect to diagnose from the record named in launch_fallback, not a headline to quote
         "degraded": bool(os.environ.get("SNS_BENCH_FALLBACK")),
+        # true = N ranks shared ONE GPU (--shared-gpu: the launch / partition / peer-window path rehearsed on a 1-GPU box): not a measurement
+        "shared_gpu_rehearsal": bool(args.shared_gpu),
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -674,7 +707,7 @@ def main():
         "config": {"workload": f"BASELINE config {cfg}: {desc} = {n_tets_global} tets, "
                                f"{n_dof_global} dofs, Re={Re:g}, Newton iteration (assemble J+F, AMG setup, "
                                f"{args.ksp} rtol 1e-8, bt line search)",
-                   "parallelism": (f"element partition x{world} ({'x-slabs' if cfg == 5 else 'RCB'}), "
+                   "parallelism": (f"element partition x{world} ({'x-slabs' if cfg == '5' else 'RCB'}), "
                                    f"{n_tets_global // world} tets per GPU" if world > 1 else "single GPU"),
                    "scaling_note": "strong: the one mesh split N ways (north_star: >= 6x at 8 GPUs on the 10 M-tet duct); "
                                    "the weak layout is under weak_scaling",
@@ -702,7 +735,7 @@ def main():
     # is the faster of the two transports, named in `transport`; both figures stay on the line.  The leg runs under a deadline
     # like the weak leg and every device-side wait inside it is bounded: a transport problem costs this key, not the line.)
     WATCHDOG.tick("headline done")
-    if dist_on and not args.no_peer:
+    if dist_on and not args.no_peer and peers is None:
         def peer_leg():
             peers = None
             try:
@@ -753,7 +786,7 @@ def main():
             try:                              # a failure of the second key must not cost the headline line ...
                 if os.environ.get("SNS_BENCH_WEAK_STALL"):          # test hook: a leg that never comes back
                     time.sleep(36000)
-                Pw, nd_w, nt_w, desc_w, _ = build_problem("5", wcells, length, Re, world, rank, local_rank, opts, True)
+                Pw, nd_w, nt_w, desc_w, _ = build_problem("5", wcells, length, Re, world, rank, local_rank, opts, True, group=peers)
                 Uw, sw = Pw.stokes_solve()
                 if sw.reason > 0:
                     ms_w, log_w, _ = timed_newton_steps(Pw, Uw, args.steps, args.warmup, world)
@@ -777,6 +810,8 @@ def main():
             WATCHDOG.tick("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(mesh, mask, g, U_host, Re, maxit=args.cpu_maxit)
         print(json.dumps(out), flush=True)
+    if peers is not None:
+        peers.close()
     if dist_on:
         dist.destroy_process_group()
     return 0

@@ -121,3 +121,30 @@ def test_protocol_selftest_between_concurrent_queues(nranks, halo_nodes):
     print(f"  {nranks} ranks, {halo_nodes} halo nodes ({32 * halo_nodes / 1e3:.0f} kB) per link: exchange {us[0]:.1f} us, all-reduce {us[1]:.1f} us, "
           f"all-gather {us[2]:.1f} us per round")
     assert 0.0 < us[0] < 5000.0 and 0.0 < us[1] < 5000.0 and 0.0 < us[2] < 5000.0
+
+
+def test_bench_py_runs_two_ranks_end_to_end_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2 --transport peer --shared-gpu`: the launcher, two rank processes on cuda:0 bootstrapped over gloo, the
+    slab partition, the timed Newton steps over peer windows, the weak leg and ONE JSON line -- the whole multi-rank flow of the
+    bench on a 1-GPU box (RCCL cannot do that).  The line says it is a rehearsal; its timings mean nothing."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SNS_BENCH_LOG_DIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--transport", "peer", "--shared-gpu", "--steps", "2",
+                        "--warmup", "1", "--cells", "64,16,16", "--no-f64-rerun", "--weak-timeout", "200", "--launch-timeout", "400"],
+                       capture_output=True, text=True, env=env, timeout=460)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    print(f"  {d['value']} {d['unit']}, {d['ms_per_step']} ms per step, its {[b for _, b, _ in d['config']['newton_log_fnorm_kspits_reason']]}, "
+          f"weak leg {d['weak_scaling']}")
+    assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["shared_gpu_rehearsal"] is True and d["degraded"] is False
+    assert d["scaling"] == "strong" and "x-slabs" in d["config"]["parallelism"]
+    # (one Newton iteration per step, snes_max_it = 1: the SNES reason is "max_it" by construction; the Krylov solves must have run)
+    assert all(b > 0 and a == a for a, b, _ in d["config"]["newton_log_fnorm_kspits_reason"])
+    assert "bitwise" in d["halo_overlap_selfcheck"]
+    assert d["weak_scaling"] and "value" in d["weak_scaling"] and d["peer_transport"] is None
+    assert d["config"]["krylov_loop_last_solve"]["halo_exchanges"] > 0
