@@ -303,6 +303,20 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert rc == 2 and "WORLD_SIZE" in err and out.strip() == ""
 
 
+def test_bench_shared_gpu_rehearsal_needs_the_peer_transport():
+    """--shared-gpu puts every rank on cuda:0, which RCCL cannot do: without --transport peer the bench refuses before it touches a GPU"""
+    rc, out, err = _run_bench(["--shared-gpu"])
+    assert rc == 2 and "--transport peer" in err and out.strip() == ""
+
+
+def test_bench_guarded_leg_reports_under_its_own_key():
+    """the peer-transport leg runs under the weak leg's guard with its own key: what the leg stores is what the line carries"""
+    o = {"peer_transport": None, "weak_scaling": None}
+    bench.run_weak_leg_guarded(o, 0, 30.0, lambda: o.__setitem__("peer_transport", {"value": 2.0}), key="peer_transport",
+                               what="peer-transport")
+    assert o == {"peer_transport": {"value": 2.0}, "weak_scaling": None}
+
+
 def test_bench_watchdog_turns_a_stalled_rank_into_a_nonzero_exit():
     """A rank that stops making progress exits non-zero by itself (no re-exec); the launcher passes the failure on."""
     import time
