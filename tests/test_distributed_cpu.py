@@ -311,6 +311,7 @@ def test_bench_shared_gpu_rehearsal_needs_the_peer_transport():
 
 def test_bench_guarded_leg_reports_under_its_own_key():
     """the peer-transport leg runs under the weak leg's guard with its own key: what the leg stores is what the line carries"""
+    import bench
     o = {"peer_transport": None, "weak_scaling": None}
     bench.run_weak_leg_guarded(o, 0, 30.0, lambda: o.__setitem__("peer_transport", {"value": 2.0}), key="peer_transport",
                                what="peer-transport")
