@@ -55,7 +55,7 @@ struct Plan {                                    // halo plan of one level (coun
     double *send_buf = nullptr, *recv_buf = nullptr;    // device, 4 doubles per node
     // peer transport: receive buffers (by parity of seq) and arrival flags live in this rank's window; the device arrays hold,
     // per neighbour k, where this rank's data / flag go in THAT rank's window
-    unsigned long long seq = 0;
+    mutable unsigned long long seq = 0;         // (advanced by every exchange, also through the const reference the solver holds)
     double* win_recv[2] = {nullptr, nullptr};
     unsigned long long* win_flag = nullptr;
     int32_t *d_send_ptr = nullptr, *d_recv_ptr = nullptr;

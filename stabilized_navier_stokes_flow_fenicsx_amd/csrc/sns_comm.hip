@@ -187,8 +187,7 @@ int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
         if (nn == 0) return SNS_OK;
         if (!p.d_put) { set_error("peer transport: halo plan was not connected"); return SNS_E_STATE; }
         CTRY(peer_check(c));
-        Plan& pm = const_cast<Plan&>(p);
-        const unsigned long long seq = ++pm.seq;
+        const unsigned long long seq = ++p.seq;
         const int par = (int)(seq & 1ull);
         const unsigned gp = (unsigned)std::max<int64_t>(1, (2 * (int64_t)ns + 255) / 256);
         hipLaunchKernelGGL(k_peer_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put + (size_t)par * nn,
