@@ -1683,6 +1683,26 @@ inline double* cycle_start_buffer(sns_ctx* h, int l, double* x) {
     return ((nu_pre - 1 + nu_post) & 1) ? h->pong[l] : x;
 }
 
+// Does level l take the fused coarse-grid correction + first post-smoothing sweep (k_post_lp / k_bpost over M = A P)?  Serial levels
+// always (given M and a low-precision format); a partitioned fine level when its single post-sweep is the exact global one (px).
+// One place for the rule: vcycle() and the callers that choose the cycle's buffers ask here.
+inline bool level_fused_post(const sns_ctx* h, int l) {
+    if (l < 0 || l + 1 >= (int)h->levels.size()) return false;
+    const Level& L = h->levels[l];
+    int nu_pre = 1, nu_post = 1;
+    level_sweeps(h, l, nu_pre, nu_post);
+    const int fmt_l = lp_format(h, L);
+    const bool have_m = h->opt.amg_fused_post && L.ap_rowptr && fmt_l != 0 && L.dinv32 &&
+                        (fmt_l == 2 ? L.ap_vals16 != nullptr : L.ap_vals32 != nullptr) && nu_post >= 1 && !level_sx(h, L);
+    return have_m && (!L.xg || (l == 0 && level_px(h, l, L) && level_nu(h, l) == 1));
+}
+// A partitioned fine level in that mode never READS the ghost tails of its cycle buffers with the "ghosts are zero" assumption (no
+// rank-local sweep runs there: the first sweep starts from zero, the post-sweep goes over M): the halo of the residual can land in
+// the iterate's own tail, the tails need no clearing, and the cycle can run in the caller's vector.
+inline bool fine_tails_unused(const sns_ctx* h) {
+    return h->levels.size() >= 2 && h->levels[0].xg && h->opt.amg_fine_cycle == 0 && !(h->rep_level == 1) && level_fused_post(h, 0);
+}
+
 int vcycle(sns_ctx* h, int l, const double* b, double* x);
 // First level (>= 1) small enough that its kernels are launch-bound rather than bandwidth-bound: it and everything
 // below run as one graph.  10 M tets: level 2 (36 k rows; level 1 has 218 k rows = 46 us per sweep); 1 M tets: level 1.
@@ -1758,13 +1778,13 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     if (h->rep_level > 0 && l == h->rep_level - 1) {
         // all-gather the right-hand side, cycle the replicated tail, keep my rows of the result
         Level& C = h->levels[h->rep_level];
-        if (rows > 0)
+        if (rows > 0 && b != h->rep_bsend)                   // (vcycle of the level above restricts straight into rep_bsend)
             HIP_TRY(hipMemcpyAsync(h->rep_bsend, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         SNS_TRY(comm_allgather(h->comm.get(), h->rep_bsend, h->rep_brecv, 4 * h->rep_maxn, h->stream));
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((4 * (int64_t)h->rep_NG + 255) / 256)), dim3(256), 0, h->stream,
                            h->rep_NG, h->rep_rowmap, h->rep_brecv, C.b);
         SNS_TRY(coarse_cycle(h, h->rep_level, C.b, C.x));
-        if (rows > 0)
+        if (rows > 0 && x)                                   // (x == nullptr: the caller reads its rows of C.x in place)
             HIP_TRY(hipMemcpyAsync(x, C.x + 4 * (size_t)h->rep_off, 4 * (size_t)rows * sizeof(double),
                                    hipMemcpyDeviceToDevice, h->stream));
         return SNS_OK;
@@ -1837,7 +1857,8 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     // values: with zero ghosts they would see the whole correction as a residual along the partition interfaces
     const bool px = level_px(h, l, L);
     const size_t ghost4 = 4 * (size_t)(L.n - rows);
-    if (px && ghost4 > 0) {
+    const bool tails_unused = (l == 0) && fine_tails_unused(h);
+    if (px && ghost4 > 0 && !tails_unused) {
         HIP_TRY(hipMemsetAsync(cur + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(oth + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
     }
@@ -1854,6 +1875,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     if (sx) {
         SNS_TRY(exchange_level(h, l, cur));
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
+    } else if (L.xg && tails_unused) {
+        // (fine level, fused post-sweep: the halo lands in the iterate's own ghost tail, no copy into the exchange vector)
+        SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, cur, cur, L.r, b, 0.0, nullptr, true));
     } else if (L.xg) {      // true residual needs the neighbours' iterate
         HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if (l == 0) {
@@ -1866,6 +1890,11 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     }
     Level& C = h->levels[l + 1];
+    // the level below is only the source of the replicated tail: its right-hand side is restricted straight into the all-gather's
+    // send buffer, and the correction is prolongated straight from this rank's rows of the replicated solution (no copies)
+    const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
+    double* cb = rep_src ? h->rep_bsend : C.b;
+    const double* cx = rep_src ? h->levels[h->rep_level].x + 4 * (size_t)h->rep_off : C.x;
     if (C.n_owned > 0) {
         // the restriction also does the next level's first sweep (z = w Dc^-1 bc into the buffer that level starts from)
         const float* dc = nullptr;
@@ -1879,16 +1908,16 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             const int32_t ns = 8 * C.n_blk;
             if (C.binv_fmt == 2)
                 hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                   L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, (const void*)C.binv32, C.omega, zc);
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
             else
                 hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                   L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, (const void*)C.binv32, C.omega, zc);
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
         } else {
             hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
-                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, C.b, dc, C.omega, zc);
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
         }
     }
-    SNS_TRY(coarse_cycle(h, l + 1, C.b, C.x));
+    SNS_TRY(coarse_cycle(h, l + 1, cb, rep_src ? nullptr : C.x));
     int s_first = 0;
     // Fused coarse-grid correction + first post-smoothing sweep (k_post_lp): z = (cur + P xc) + om Dinv (r - M xc) with
     // M = A P and r the residual restricted above -- the sweep reads M (0.37x the blocks of A on the fine level) instead
@@ -1896,14 +1925,12 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     // post-sweep is the exact global one (px): the ghost aggregates' corrections arrive by ONE level-(l+1) exchange
     // instead of the level-l halo of the corrected iterate.
     const int fmt_l = lp_format(h, L);
-    const bool have_m = h->opt.amg_fused_post && L.ap_rowptr && fmt_l != 0 && L.dinv32 &&
-                        (fmt_l == 2 ? L.ap_vals16 != nullptr : L.ap_vals32 != nullptr) && nu_post >= 1 && !sx;
-    const bool fused_post = have_m && (!L.xg || (l == 0 && px && nu == 1));
+    const bool fused_post = level_fused_post(h, l);
     if (fused_post) {
-        const double* xc = C.x;
+        const double* xc = cx;
         if (L.xg) {                                    // distributed fine level: xc incl. the neighbours' aggregates
             if (C.n_owned > 0)
-                HIP_TRY(hipMemcpyAsync(C.xg, C.x, 4 * (size_t)C.n_owned * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                HIP_TRY(hipMemcpyAsync(C.xg, cx, 4 * (size_t)C.n_owned * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             SNS_TRY(exchange_level(h, l + 1, C.xg));
             xc = C.xg;
         }
@@ -1944,7 +1971,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         std::swap(cur, oth);
         s_first = 1;
     } else if (rows > 0) {
-        hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, C.x, cur);
+        hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, cx, cur);
     }
     if (fused_post) {
         // (the post-sweep is done; a partitioned fine level got its neighbours' corrections through xc)
@@ -1984,6 +2011,8 @@ int pc_apply(sns_ctx* h, const double* r, double* z) {
                 // distributed: the per-rank V-cycle must see ZERO ghost values on level 0 (block-Jacobi across
                 // ranks, like PETSc's parallel default bjacobi).  z's ghost tail may hold halo data, so cycle
                 // in internal buffers whose tails are never written and copy the owned part out.
+                // (fine_tails_unused: nothing in the fine level's cycle reads a ghost tail as zero -- no internal buffer, no copy)
+                if (fine_tails_unused(h)) return vcycle(h, 0, r, z);
                 SNS_TRY(vcycle(h, 0, r, h->levels[0].x));
                 HIP_TRY(hipMemcpyAsync(z, h->levels[0].x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 return SNS_OK;
@@ -2052,7 +2081,7 @@ double* fused_first_sweep_target(sns_ctx* h, double* zdst) {
     const Level& L = h->levels[0];
     if (block_active(h, 0) || lp_format(h, L) == 0 || !L.dinv32 || L.n_owned <= 0) return nullptr;
     if (h->rep_level == 1) return nullptr;                       // level 0 is only the source of the replicated copy
-    double* x = (h->n > h->n_owned) ? h->levels[0].x : zdst;     // (pc_apply cycles a partitioned handle in its own buffer)
+    double* x = (h->n > h->n_owned && !fine_tails_unused(h)) ? h->levels[0].x : zdst;   // (as pc_apply chooses the cycle's vector)
     return cycle_start_buffer(h, 0, x);
 }
 
@@ -2744,7 +2773,9 @@ int sns_set_options(sns_handle h, const sns_options* o) {
                             (o->amg_fused_post != h->opt.amg_fused_post) || (o->amg_block_smooth != h->opt.amg_block_smooth);
     const bool damping_changed = (o->amg_omega != h->opt.amg_omega);
     const bool sweep_exchange_changed = (o->amg_sweep_exchange_rows != h->opt.amg_sweep_exchange_rows) ||
-                                        (o->amg_post_exchange != h->opt.amg_post_exchange);
+                                        (o->amg_post_exchange != h->opt.amg_post_exchange) ||
+                                        (o->amg_fused_post != h->opt.amg_fused_post) || (o->amg_f32_matrix != h->opt.amg_f32_matrix) ||
+                                        (o->amg_fine_cycle != h->opt.amg_fine_cycle) || (o->pc_type != h->opt.pc_type);
     h->opt = *o;
     if (h->damping_backoff != 1.0) {                 // a retry's stronger damping does not outlive an options call
         h->damping_backoff = 1.0;
