@@ -1658,7 +1658,7 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
 // Does the restriction from level l also do level l + 1's first sweep (k_restrict with dinv32_c)?  Only where that sweep is
 // the plain rank-local w Dc^-1 bc of a smoothed level on its fp32 D^-1 copy: not the dense coarsest level, not the level whose
 // cycle is the all-gather into the replicated tail (nor that tail's first level, whose right-hand side comes from the gather),
-// not a partitioned level (ghost tails, exchanges), not the experimental fine-cycle shapes.
+// not a partitioned level whose sweeps exchange ghost values, not the experimental fine-cycle shapes.
 inline bool restrict_fuses_first(const sns_ctx* h, int l) {
     const int nl = (int)h->levels.size();
     const int c = l + 1;
@@ -1669,7 +1669,10 @@ inline bool restrict_fuses_first(const sns_ctx* h, int l) {
     if (h->rep_level > 0 && (c == h->rep_level - 1 || l == h->rep_level - 1)) return false;
     if (l == 0 && h->opt.amg_fine_cycle != 0) return false;
     const Level& C = h->levels[c];
-    if (C.xg || C.n != C.n_owned) return false;
+    // (a partitioned coarse level qualifies too: its first sweep starts from zero and is rank-local by construction -- owned right-hand
+    // side, owned rows of the start buffer, the ghost tail stays as it is --, unless its sweeps exchange ghost values, whose damping
+    // and buffers follow the exchanging code path)
+    if ((C.xg || C.n != C.n_owned) && level_sx(h, C)) return false;
     if (block_active(h, c)) return C.binv32 != nullptr;    // k_restrict_blk: restriction in the order of the coarse aggregates
     return lp_format(h, C) != 0 && C.dinv32 != nullptr;
 }
