@@ -197,6 +197,9 @@ typedef struct {
                                one GPU 19.3-20.2 -> 17.9-18.0 ms per Newton iteration), where a whole mesh on one GPU loses
                                (10 M tets: 42 -> 37 iterations, 129 -> 132 ms; 893 k nodes +2.5 %), which is why a single-GPU
                                handle takes them with amg_block_smooth = 2 only.  Fixed when the hierarchy is built */
+    int    amg_fuse_restrict; /* 1 (default): below the fine level the residual r = b - A x, its restriction and the next level's
+                               first sweep are ONE launch (k_resid_restrict, csrc/sns_block.hip) instead of two -- every launch down
+                               there is 5-8 us of latency.  Same sums in the same order; 0 = the separate kernels */
 } sns_options;
 
 void sns_default_options(sns_options* opt);

@@ -49,6 +49,7 @@ class SnsOptions(C.Structure):
         ("amg_growth_check", C.c_int),
         ("amg_block_max_rows", C.c_int),
         ("amg_block_fine_rows", C.c_int),
+        ("amg_fuse_restrict", C.c_int),
     ]
 
 

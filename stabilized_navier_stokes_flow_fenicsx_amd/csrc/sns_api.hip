@@ -1739,6 +1739,7 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     sig.push_back(h->opt.amg_fine_cycle);
     sig.push_back(h->opt.amg_block_smooth); sig.push_back(h->opt.amg_bnu_l1); sig.push_back(h->opt.amg_bnu_l2);
     sig.push_back(h->opt.amg_bnu_deep); sig.push_back(h->opt.amg_block_max_rows); sig.push_back(h->opt.amg_block_fine_rows);
+    sig.push_back(h->opt.amg_fuse_restrict);
     sig.push_back(restrict_fuses_first(h, gl - 1) ? 1.0 : 0.0);
     sig.push_back(gl);
     if (!h->coarse_graph || sig != h->graph_sig) {
@@ -1875,9 +1876,16 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         launch_sweep(h, l, L, rows, cur, oth, b, om);
         std::swap(cur, oth);
     }
+    Level& C = h->levels[l + 1];
+    // Below the fine level the residual and the restriction (+ the next level's first sweep) are ONE launch (k_resid_restrict):
+    // `xres` is then the vector the residual reads and the pass itself is issued with the restriction further down.
+    const int fmt_rr = lp_format(h, L);
+    const bool rr_fused = l >= 1 && h->opt.amg_fuse_restrict != 0 && fmt_rr != 0 && rows > 0 && C.n_owned > 0 && L.m_ptr &&
+                          (!block_active(h, l + 1) || !restrict_fuses_first(h, l) || C.binv_fmt == fmt_rr);
+    const double* xres = cur;
     if (sx) {
         SNS_TRY(exchange_level(h, l, cur));
-        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
+        if (!rr_fused) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     } else if (L.xg && tails_unused) {
         // (fine level, fused post-sweep: the halo lands in the iterate's own ghost tail, no copy into the exchange vector)
         SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, cur, cur, L.r, b, 0.0, nullptr, true));
@@ -1887,12 +1895,12 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, L.xg, L.xg, L.r, b, 0.0, nullptr, true));
         } else {
             SNS_TRY(exchange_level(h, l, L.xg));
-            launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
+            xres = L.xg;
+            if (!rr_fused) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
         }
-    } else {
+    } else if (!rr_fused) {
         launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
     }
-    Level& C = h->levels[l + 1];
     // the level below is only the source of the replicated tail: its right-hand side is restricted straight into the all-gather's
     // send buffer, and the correction is prolongated straight from this rank's rows of the replicated solution (no copies)
     const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
@@ -1907,7 +1915,21 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             dc = C.dinv32;
             zc = cycle_start_buffer(h, l + 1, C.x);          // (coarse_cycle below is called with x = C.x)
         }
-        if (fuse && block_active(h, l + 1)) {
+        if (rr_fused) {
+            // mode of the coarse level's first sweep: 0 none, 1 nodal D^-1, 2 its aggregate blocks (walked in THEIR order)
+            const int mode = !fuse ? 0 : (block_active(h, l + 1) ? 2 : 1);
+            const int32_t* slots = mode == 2 ? C.blk_rows : nullptr;
+            const int32_t n_slots = mode == 2 ? 8 * C.n_blk : C.n_owned;
+            const unsigned grid = (unsigned)((n_slots + 7) / 8);
+            const void* vals = fmt_rr == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
+            const float* sc16 = fmt_rr == 2 ? L.scale16 : nullptr;
+#define SNS_RR(F, M)                                                                                                            \
+    hipLaunchKernelGGL((k_resid_restrict<F, M>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc)
+            if (fmt_rr == 2) { if (mode == 2) SNS_RR(2, 2); else if (mode == 1) SNS_RR(2, 1); else SNS_RR(2, 0); }
+            else             { if (mode == 2) SNS_RR(1, 2); else if (mode == 1) SNS_RR(1, 1); else SNS_RR(1, 0); }
+#undef SNS_RR
+        } else if (fuse && block_active(h, l + 1)) {
             const int32_t ns = 8 * C.n_blk;
             if (C.binv_fmt == 2)
                 hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
@@ -2554,6 +2576,7 @@ void sns_default_options(sns_options* o) {
     o->amg_growth_check = 1;
     o->amg_block_max_rows = 0;
     o->amg_block_fine_rows = 600000;
+    o->amg_fuse_restrict = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }

@@ -295,6 +295,79 @@ template __global__ void k_restrict_blk<1>(int32_t, const int32_t*, const int32_
 template __global__ void k_restrict_blk<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, const double*,
                                            double*, const void*, double, double*);
 
+// Residual + restriction (+ the coarse level's first sweep) of a level >= 1 in ONE launch:
+//     r = b - A x,      bc[I] = sum_{i in I} free_i r[i],      z_c = w_c S_c bc   (MODE 0: none, 1: nodal D_c^-1, 2: aggregate blocks B_c^-1)
+// in place of k_spmv_lp<B_MINUS_AX> followed by k_restrict / k_restrict_blk -- below the fine level every launch is ~5-8 us of
+// latency and the residual is read back by nobody but the restriction (and, later, by the fused post-sweep: r is still written).
+// A workgroup takes one smoother block of the COARSE level (8 coarse nodes, slots blk_rows_c[8 G ..]; MODE != 2: 8 consecutive coarse
+// nodes), a half-wave one coarse node, a quad one member row of that node -- 64 fine rows per workgroup with the row loop of
+// k_spmv_lp / k_bsweep, i.e. the residual pass keeps its parallelism.  The member sums are formed in member order (as k_restrict
+// forms them: same bits); nodes of more than 8 members take further rounds.
+template <int FMT, int MODE>
+__global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cslots, const int32_t* __restrict__ blk_rows_c,
+                                                        const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
+                                                        const uint8_t* __restrict__ free_mask, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ colind, const void* __restrict__ vals_v,
+                                                        const float* __restrict__ scale, const double* __restrict__ x,
+                                                        const double* __restrict__ bvec, double* __restrict__ r_out,
+                                                        double* __restrict__ bc, const float* __restrict__ dinv32_c,
+                                                        const void* __restrict__ binv_c, double omega_c, double* __restrict__ z_c) {
+    __shared__ double sred[8][8][4];
+    __shared__ double sbc[32];
+    const int tid = threadIdx.x, hw = tid >> 5, q = (tid & 31) >> 2, c = tid & 3;
+    const int32_t slot = (int32_t)blockIdx.x * 8 + hw;
+    int32_t I = -1;
+    if (slot < n_cslots) I = blk_rows_c ? blk_rows_c[slot] : (slot < nc ? slot : -1);
+    BinvRow<FMT> Bv;
+    if (MODE == 2) Bv.load(binv_c, (int64_t)blockIdx.x, tid & 31, hw == 0);           // (half-wave 0 applies the coarse block)
+    const int32_t k0 = I >= 0 ? m_ptr[I] : 0, k1 = I >= 0 ? m_ptr[I + 1] : 0;
+    double s = 0.0;
+    for (int32_t kb = k0; __syncthreads_or(kb < k1); kb += 8) {
+        const int32_t row = (kb + q < k1) ? m_idx[kb + q] : -1;
+        const bool live = row >= 0;
+        const int32_t rs = live ? rowptr[row] : 0, re = live ? rowptr[row + 1] : 0;
+        double v = 0.0;
+        if (live) {
+            double sc = 1.0;
+            if (FMT == 2) sc = (double)scale[4 * (int64_t)row + c];
+            const double pre_b = bvec[4 * (int64_t)row + c];
+            const double res = pre_b - sc * lp_row_times_x<FMT>(rs, re, colind, vals_v, x, c);
+            r_out[4 * (int64_t)row + c] = res;
+            v = (!free_mask || free_mask[4 * (int64_t)row + c]) ? res : 0.0;
+        }
+        sred[hw][q][c] = v;
+        __syncthreads();
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s += sred[hw][t][c];
+        }
+        __syncthreads();
+    }
+    if (q == 0 && I >= 0) bc[4 * (int64_t)I + c] = s;
+    if (MODE == 1) {
+        if (q == 0 && I >= 0) {                                                      // whole quads: the four sums of the node
+            const float4 D = *reinterpret_cast<const float4*>(dinv32_c + 16 * (int64_t)I + 4 * c);
+            const double s0 = qb<0>(s), s1 = qb<1>(s), s2 = qb<2>(s), s3 = qb<3>(s);
+            z_c[4 * (int64_t)I + c] = omega_c * ((double)D.x * s0 + (double)D.y * s1 + (double)D.z * s2 + (double)D.w * s3);
+        }
+    } else if (MODE == 2) {
+        if (q == 0) sbc[4 * hw + c] = I >= 0 ? s : 0.0;
+        __syncthreads();
+        if (hw == 0) {
+            const int j = tid & 31;
+            const double zz = Bv.dot(sbc);
+            const int32_t J = ((int32_t)blockIdx.x * 8 + (j >> 2) < n_cslots) ? blk_rows_c[(int64_t)blockIdx.x * 8 + (j >> 2)] : -1;
+            if (J >= 0) z_c[4 * (int64_t)J + (j & 3)] = omega_c * zz;
+        }
+    }
+}
+#define SNS_INST_RR(F, M)                                                                                                        \
+    template __global__ void k_resid_restrict<F, M>(int32_t, int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, \
+                                                    const int32_t*, const int32_t*, const void*, const float*, const double*,    \
+                                                    const double*, double*, double*, const float*, const void*, double, double*);
+SNS_INST_RR(1, 0) SNS_INST_RR(1, 1) SNS_INST_RR(1, 2) SNS_INST_RR(2, 0) SNS_INST_RR(2, 1) SNS_INST_RR(2, 2)
+#undef SNS_INST_RR
+
 // B_G^-1 of every smoother block from the level's fp64 operator: 8 blocks per workgroup, 32 lanes each (lane j = column j of the
 // 32 x 32 block in LDS).  Member slots a block does not fill keep identity rows / columns.  (Blocks = the aggregates; the rare
 // aggregate of more than 8 nodes -- a leftover node joins a full neighbour -- is split into chunks of 8 in member order: the
