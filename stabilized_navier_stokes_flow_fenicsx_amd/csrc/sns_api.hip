@@ -1880,7 +1880,9 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     // Below the fine level the residual and the restriction (+ the next level's first sweep) are ONE launch (k_resid_restrict):
     // `xres` is then the vector the residual reads and the pass itself is issued with the restriction further down.
     const int fmt_rr = lp_format(h, L);
-    const bool rr_fused = l >= 1 && h->opt.amg_fuse_restrict != 0 && fmt_rr != 0 && rows > 0 && C.n_owned > 0 && L.m_ptr &&
+    // (amg_fuse_restrict = 2: a single-GPU fine level as well -- its residual kernel is the tuned k_spmv_lp, kept by default)
+    const bool rr_level = l >= 1 || (h->opt.amg_fuse_restrict >= 2 && !L.xg && h->opt.amg_fine_cycle == 0);
+    const bool rr_fused = rr_level && h->opt.amg_fuse_restrict != 0 && fmt_rr != 0 && rows > 0 && C.n_owned > 0 && L.m_ptr &&
                           (!block_active(h, l + 1) || !restrict_fuses_first(h, l) || C.binv_fmt == fmt_rr);
     const double* xres = cur;
     if (sx) {
@@ -1926,8 +1928,10 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
 #define SNS_RR(F, M)                                                                                                            \
     hipLaunchKernelGGL((k_resid_restrict<F, M>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
                        L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc)
+            if (l == 0) time_begin(h, SPMV_B_MINUS_AX);                      // (bench.py's per-launch accounting of the fine-level passes)
             if (fmt_rr == 2) { if (mode == 2) SNS_RR(2, 2); else if (mode == 1) SNS_RR(2, 1); else SNS_RR(2, 0); }
             else             { if (mode == 2) SNS_RR(1, 2); else if (mode == 1) SNS_RR(1, 1); else SNS_RR(1, 0); }
+            if (l == 0) time_end(h);
 #undef SNS_RR
         } else if (fuse && block_active(h, l + 1)) {
             const int32_t ns = 8 * C.n_blk;
