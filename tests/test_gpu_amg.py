@@ -160,3 +160,24 @@ def test_slow_but_converging_solve_is_not_retried(gpu):
     assert k.reason > 0 and k.its > 1.5 * k2.its
     assert c["damping_retries"] == 0 and c["damping_factor"] == 1.0 and c["first_attempt_reason"] == 0
     P.close()
+
+
+@pytest.mark.parametrize("block,dense_rows,fmt", [(1, 100, 2), (1, 0, 1), (0, 0, 2)])
+def test_fused_residual_restriction_is_the_same_cycle(gpu, block, dense_rows, fmt):
+    """amg_fuse_restrict: below the fine level residual, restriction and the next level's first sweep are one launch
+    (k_resid_restrict) instead of k_spmv_lp + k_restrict / k_restrict_blk.  Same row products, the member sums in the same order:
+    the cycle is the same linear operator to round-off (observed: bitwise), for nodal and aggregate-block coarse levels, a dense or a
+    smoothed last level, fp32 and fp16 matrix copies -- and the Krylov solve takes the same iterations."""
+    m, mask, P, U, F = _problem(gpu, dict(amg_block_smooth=block, amg_dense_rows=dense_rows, amg_f32_matrix=fmt, amg_fuse_restrict=1))
+    P.pc_setup()
+    r = torch.from_numpy(np.random.default_rng(11).normal(size=m.num_dofs)).cuda()
+    z1 = P.pc_apply(r).cpu().numpy()
+    y1, k1 = P.krylov_solve(F)
+    P.set_options(amg_fuse_restrict=0)
+    z0 = P.pc_apply(r).cpu().numpy()
+    y0, k0 = P.krylov_solve(F)
+    print(f"  block {block} dense_rows {dense_rows} fmt {fmt}: levels {[h['rows'] for h in P.hierarchy()]} fused vs separate {rel(z1, z0):.1e}, "
+          f"its {k1.its} / {k0.its}")
+    assert rel(z1, z0) < 1e-13
+    assert k1.reason > 0 and k0.reason > 0 and k1.its == k0.its
+    P.close()
