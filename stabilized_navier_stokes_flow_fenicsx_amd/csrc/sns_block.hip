@@ -29,6 +29,14 @@ namespace {
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+// workgroup b of nb -> the b-th workgroup of ITS XCD's contiguous eighth of the grid (hardware deals consecutive workgroup ids round-robin
+// to the 8 XCDs): neighbouring aggregates, whose x gathers overlap, share an L2 (as xcd_remap of sns_kernels.hip)
+__device__ __forceinline__ int xcd_remap_b(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double quad_perm_b(double v) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
                                                 double* __restrict__ y, const double* __restrict__ bvec, double omega) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
-    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
                                                double* __restrict__ y) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
-    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* 
                                                 double* __restrict__ z) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
-    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
     const int32_t row = in ? blk_rows[slot] : -1;
     const bool live = row >= 0;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
                                                       double* __restrict__ z_c) {
     __shared__ double sres[8 * 32];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
-    const int32_t slot = ((int32_t)blockIdx.x * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
     const int32_t I = in ? blk_rows_c[slot] : -1;
     const bool live = I >= 0;
@@ -315,11 +323,12 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
     __shared__ double sred[8][8][4];
     __shared__ double sbc[32];
     const int tid = threadIdx.x, hw = tid >> 5, q = (tid & 31) >> 2, c = tid & 3;
-    const int32_t slot = (int32_t)blockIdx.x * 8 + hw;
+    const int32_t G = (int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x);          // the coarse smoother block of this workgroup
+    const int32_t slot = G * 8 + hw;
     int32_t I = -1;
     if (slot < n_cslots) I = blk_rows_c ? blk_rows_c[slot] : (slot < nc ? slot : -1);
     BinvRow<FMT> Bv;
-    if (MODE == 2) Bv.load(binv_c, (int64_t)blockIdx.x, tid & 31, hw == 0);           // (half-wave 0 applies the coarse block)
+    if (MODE == 2) Bv.load(binv_c, (int64_t)G, tid & 31, hw == 0);           // (half-wave 0 applies the coarse block)
     const int32_t k0 = I >= 0 ? m_ptr[I] : 0, k1 = I >= 0 ? m_ptr[I + 1] : 0;
     double s = 0.0;
     for (int32_t kb = k0; __syncthreads_or(kb < k1); kb += 8) {
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
         if (hw == 0) {
             const int j = tid & 31;
             const double zz = Bv.dot(sbc);
-            const int32_t J = ((int32_t)blockIdx.x * 8 + (j >> 2) < n_cslots) ? blk_rows_c[(int64_t)blockIdx.x * 8 + (j >> 2)] : -1;
+            const int32_t J = (G * 8 + (j >> 2) < n_cslots) ? blk_rows_c[(int64_t)G * 8 + (j >> 2)] : -1;
             if (J >= 0) z_c[4 * (int64_t)J + (j & 3)] = omega_c * zz;
         }
     }
