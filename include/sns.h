@@ -288,6 +288,11 @@ int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
 int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]);
 int sns_peer_connect(void* peer, const char* ipc_handles);
 int sns_peer_destroy(void* peer);
+/* Link check between the REAL ranks of a connected communicator (collective, after sns_peer_connect and one synchronisation of the
+ * ranks): `rounds` all-reduces whose contributions depend on rank and round and `rounds` all-gathers of 4096 patterned doubles per rank,
+ * every value verified.  The first thing to run on a new machine: a visibility problem of the windows shows up here as SNS_E_COMM with
+ * a count instead of as a solve that quietly diverges.                                                                              */
+int sns_peer_check_links(void* peer, int rounds);
 /* Self-test and latency probe of the protocol inside ONE process: nranks (2 or 3) threads with a window, a stream and a
  * communicator end each, wired directly (no IPC), a ring of halo links of `halo_nodes` nodes per direction.  Per collective -- halo
  * exchange, all-reduce (4 doubles), all-gather (2048 doubles per rank) -- `reps` rounds with every payload verified, then `reps`

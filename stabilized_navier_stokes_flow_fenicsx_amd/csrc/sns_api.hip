@@ -2954,6 +2954,7 @@ int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void
 }
 int sns_peer_connect(void* peer, const char* ipc_handles) { return peer_connect(static_cast<Peer*>(peer), ipc_handles); }
 int sns_peer_destroy(void* peer) { return peer_destroy(static_cast<Peer*>(peer)); }
+int sns_peer_check_links(void* peer, int rounds) { return peer_check_links(static_cast<Peer*>(peer), rounds); }
 int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]) {
     return peer_selftest(device, nranks, halo_nodes, reps, us_out);
 }

@@ -104,6 +104,8 @@ int peer_finish_connect(Peer* p);               // (second half of peer_connect:
 int peer_destroy(Peer* p);
 // in-process self-test + latency probe: nranks threads, a ring of halo links; us_out = {exchange, all-reduce, all-gather} per round
 int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
+// verified all-reduces / all-gathers between the REAL ranks of a connected communicator (collective)
+int peer_check_links(Peer* p, int rounds);
 // wire a freshly uploaded plan to the neighbours' windows.  `table_allgather(mine, all)` is the caller's host all-gather of
 // 3 * nranks doubles per rank (collective: every rank connects the same plan at the same time).
 struct PlanOffers {                              // where rank j writes in MY window: payload parity 0 / 1, flag; -1 = no link

@@ -716,4 +716,63 @@ int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_ou
     return SNS_OK;
 }
 
+// Link check of a CONNECTED communicator between its real ranks (collective; sns_peer_check_links): `rounds` all-reduces whose
+// contributions depend on rank and round and `rounds` all-gathers of 4096 patterned doubles per rank, every value verified.  What it
+// is for: the first contact of the windows with real xGMI links -- a visibility problem (a stale flag or payload read) shows up here
+// as SNS_E_COMM with a count, not later as a solve that quietly diverges.
+int peer_check_links(Peer* pe, int rounds) {
+    if (!pe || !pe->connected || rounds < 1) { set_error("sns_peer_check_links: connected communicator, rounds >= 1"); return SNS_E_ARG; }
+    CHIP(hipSetDevice(pe->device));
+    Comm c;
+    c.peer = pe;
+    c.rank = pe->rank;
+    c.nranks = pe->nranks;
+    const int n = 4096, nr = pe->nranks;
+    hipStream_t st = nullptr;
+    double *ar = nullptr, *ags = nullptr, *agr = nullptr;
+    int* bad = nullptr;
+    int rc = SNS_OK, wrong = 0;
+    auto body = [&]() -> int {
+        CHIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        CHIP(hipMalloc((void**)&ar, 8 * sizeof(double)));
+        CHIP(hipMalloc((void**)&ags, n * sizeof(double)));
+        CHIP(hipMalloc((void**)&agr, (size_t)n * nr * sizeof(double)));
+        CHIP(hipMalloc((void**)&bad, sizeof(int)));
+        CHIP(hipMemset(bad, 0, sizeof(int)));
+        for (int it = 0; it < rounds; ++it) {
+            const double tag = 3.0e6 * (it + 1);
+            hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(256), 0, st, 2, tag + (double)pe->rank, ar);             // 8 values
+            CTRY(comm_allreduce_sum(&c, ar, 8, st));
+            double got[8];
+            CHIP(hipMemcpyAsync(got, ar, sizeof(got), hipMemcpyDeviceToHost, st));
+            CHIP(hipStreamSynchronize(st));
+            CTRY(peer_check(&c));
+            for (int q = 0; q < 8; ++q) {
+                double expect = 0.0;
+                for (int r = 0; r < nr; ++r) expect += tag + (double)r + (double)q;
+                if (got[q] != expect) ++wrong;
+            }
+            hipLaunchKernelGGL(k_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, st, n / 4, tag + 1.0e3 * pe->rank, ags);
+            CTRY(comm_allgather(&c, ags, agr, n, st));
+            for (int r = 0; r < nr; ++r)
+                hipLaunchKernelGGL(k_selftest_check, dim3((n + 255) / 256), dim3(256), 0, st, n / 4, tag + 1.0e3 * r, agr + (size_t)r * n, bad);
+        }
+        CHIP(hipStreamSynchronize(st));
+        CTRY(peer_check(&c));
+        int dbad = 0;
+        CHIP(hipMemcpy(&dbad, bad, sizeof(int), hipMemcpyDeviceToHost));
+        wrong += dbad;
+        return SNS_OK;
+    };
+    rc = body();
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    (void)hipFree(ar); (void)hipFree(ags); (void)hipFree(agr); (void)hipFree(bad);
+    if (rc == SNS_OK && wrong != 0) {
+        set_error("peer link check: rank " + std::to_string(pe->rank) + " read " + std::to_string(wrong) + " wrong values in " +
+                  std::to_string(rounds) + " rounds (stores of a peer not visible: window memory type / peer access)");
+        rc = SNS_E_COMM;
+    }
+    return rc;
+}
+
 }  // namespace sns

@@ -396,7 +396,7 @@ class PeerGroup:
         P.close(); peers.close()                           # collective
     """
 
-    def __init__(self, device=None, *, group=None, window_bytes: int = 0):
+    def __init__(self, device=None, *, group=None, window_bytes: int = 0, check_rounds: int = 50):
         import torch.distributed as dist
         self.lib = _lib.load()
         self.dist_group = group
@@ -412,6 +412,16 @@ class PeerGroup:
         dist.all_gather_object(box, bytes(hd.raw), group=group)          # (implies: every window exists and is zeroed)
         check(self.lib.sns_peer_connect(self.ptr, b"".join(box)))
         dist.barrier(group=group)                                        # every rank has mapped every window
+        if check_rounds > 0:
+            # verified all-reduces / all-gathers between the real ranks before anything relies on the links (sns_peer_check_links);
+            # every rank learns the common verdict, so a failure raises everywhere instead of stranding the healthy ranks
+            rc = self.lib.sns_peer_check_links(self.ptr, int(check_rounds))
+            msg = self.lib.sns_last_error().decode() if rc != 0 else ""
+            box2 = [None] * self.nranks
+            dist.all_gather_object(box2, (rc, msg), group=group)
+            bad = [(r, m) for r, (c, m) in enumerate(box2) if c != 0]
+            if bad:
+                raise RuntimeError("peer-window link check failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
 
     def close(self):
         """Collective; call after the problems attached to this communicator are closed."""
