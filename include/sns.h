@@ -201,6 +201,18 @@ typedef struct {
                                first sweep are ONE launch (k_resid_restrict, csrc/sns_block.hip) instead of two -- every launch down
                                there is 5-8 us of latency.  Same sums in the same order; 0 = the separate kernels; 2 = a single-GPU FINE level as
                                well (measured, no: 0.326 ms against 0.234 + 0.030 for the tuned fine-level residual + restriction) */
+    int    halo_windows;    /* (round 5) multi-GPU over the window transports (peer windows; the in-process team): 1 (default) = a halo
+                               exchange is ONE launch -- the put into the neighbours' receive windows -- and the level pass that consumes
+                               it reads the ghost entries straight from its own window, the waves that meet a ghost column waiting for
+                               the neighbours' arrival flags themselves: no unpack kernel, no interior / boundary split, no second
+                               stream, no staging copies.  0 = put + wait / unpack into the vector's ghost tail, then the passes of
+                               round 4 (the RCCL transport always works that way, with pack + send / recv + unpack) */
+    int    amg_exact_sweeps; /* (round 5) 1 (default): on the window transports the aggregate-block-smoothed PARTITIONED levels >= 1 run
+                               the single-GPU schedule (level 1: 1 + amg_bnu_l1 sweeps, the coarse-grid correction inside the first
+                               post-sweep) with EXACT global sweeps -- one put per sweep, which costs one small launch there --
+                               instead of amg_bnu_l2 + amg_bnu_l2 rank-local sweeps with an unfused correction (8-way split of the
+                               10 M-tet duct: 34 / 36 instead of 36 / 36 BiCGStab iterations with 5 instead of 9 level-1 launches per
+                               cycle).  0, and always over RCCL (an exchange per sweep costs a send / recv group there): round 4's cycle */
 } sns_options;
 
 void sns_default_options(sns_options* opt);
@@ -210,7 +222,7 @@ const char* sns_version(void);
  * and the fixed-size out-arrays of the getters below have grown (sns_get_counters / sns_get_kernel_times: 4 -> 8 entries in
  * round 3), so a binding built against an older header would pass short buffers: bindings compare both numbers with the
  * header they were written against before making any other call (the ctypes mirror does, _lib.py) and refuse on a mismatch. */
-#define SNS_ABI_VERSION 5
+#define SNS_ABI_VERSION 6
 int sns_abi_version(void);
 int64_t sns_options_size(void);
 

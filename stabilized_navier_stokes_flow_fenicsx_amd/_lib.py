@@ -50,6 +50,8 @@ class SnsOptions(C.Structure):
         ("amg_block_max_rows", C.c_int),
         ("amg_block_fine_rows", C.c_int),
         ("amg_fuse_restrict", C.c_int),
+        ("halo_windows", C.c_int),
+        ("amg_exact_sweeps", C.c_int),
     ]
 
 
@@ -60,7 +62,7 @@ class SnsTimings(C.Structure):
 
 
 # constants of sns.h
-ABI_VERSION = 5                          # SNS_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 6                          # SNS_ABI_VERSION of the header this mirror was written against
 FORM_STOKES, FORM_NS = 0, 1
 KSP_BICGSTAB, KSP_FGMRES, KSP_TFQMR = 0, 1, 2
 PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2

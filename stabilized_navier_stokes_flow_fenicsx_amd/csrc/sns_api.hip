@@ -156,6 +156,7 @@ struct sns_ctx {
     int32_t* rep_valmap = nullptr;                // [nranks*maxnz] gathered slot -> slot of the replicated level (-1: padding)
     int32_t* rep_rowmap = nullptr;                // [NG] row of the replicated level -> gathered row (rank*maxn + i)
     double *rep_vsend = nullptr, *rep_vrecv = nullptr, *rep_bsend = nullptr, *rep_brecv = nullptr;
+    int64_t *rep_doff = nullptr, *rep_dcnt = nullptr;   // [nranks] doubles: where rank r's right-hand side goes in the replicated level's b, and how much
     int32_t* cg_colmap = nullptr;                 // local coarsest node -> global (padded) node id
     double *cg_rows = nullptr, *cg_full = nullptr, *cg_send = nullptr, *cg_recv = nullptr;
     std::vector<std::vector<int32_t>> ghost_gid;  // per level: (owner rank, owner-local id) of each ghost node
@@ -257,8 +258,16 @@ int reduce_bicg(sns_ctx* h, int nblocks, double* red, double* sc) {
     if (pe) {                                    // peer windows: the all-reduce rides inside the same single-workgroup launch
         SNS_TRY(peer_check(h->comm.get()));
         ++h->ctr_allreduce;
+        if (pe->host_sync) {                     // team: reduce + contribute | host barrier | sum + scalar update
+            hipLaunchKernelGGL((k_reduce_final_bicg_peer<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc,
+                               peer_allreduce_args(pe, 1));
+            SNS_TRY(comm_host_barrier(h->comm.get(), h->stream));
+            hipLaunchKernelGGL((k_reduce_final_bicg_peer<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc,
+                               peer_allreduce_args(pe, 2));
+            return SNS_OK;
+        }
         hipLaunchKernelGGL((k_reduce_final_bicg_peer<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc,
-                           peer_next_allreduce(pe));
+                           peer_allreduce_args(pe, 0));
         return SNS_OK;
     }
     hipLaunchKernelGGL((k_reduce_final_bicg<WHICH>), dim3(1), dim3(256), 0, h->stream, nb, src, red, sc);
@@ -293,10 +302,12 @@ int halo_exchange(sns_ctx* h, double* x) { return exchange_level(h, 0, x); }
 
 // Multi-GPU, level 0: a pass is either over every row (split 0), over the interior rows only (1: rows with a ghost
 // column, flagged in h->bnd_flag, are skipped) or over the boundary rows listed in h->bnd_rows (2).
+// Window transports (round 5): 3 = every row in one launch, the ghost entries read straight from the receive window `gs`.
 struct Split {
     int mode = 0;
     hipStream_t stream = nullptr;       // nullptr = the handle's stream
     int partial_off = 0;
+    GhostSrc gs;
 };
 
 // y = A_l x (or fused variants).  rows = number of block rows computed.
@@ -311,29 +322,34 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
     if (fine && sp.mode == 1) {
         time_begin(h, MODE, st);                      // multi-GPU: the interior pass is the bulk of a split launch
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
-                           b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, h->bnd_flag, sp.partial_off);
+                           b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, h->bnd_flag, sp.partial_off, GhostSrc());
         time_end(h, st);
     } else if (fine && sp.mode == 2) {
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 2>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
-                           b, L.dinv, omega, dotw, h->partial, h->bnd_rows, (const uint8_t*)nullptr, sp.partial_off);
+                           b, L.dinv, omega, dotw, h->partial, h->bnd_rows, (const uint8_t*)nullptr, sp.partial_off, GhostSrc());
+    } else if (fine && sp.mode == 3) {
+        time_begin(h, MODE, st);
+        hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 3>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals, x, y,
+                           b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0, sp.gs);
+        time_end(h, st);
     } else if (fine) {
         time_begin(h, MODE);
 #ifdef SNS_HARNESS                                     // in-solver A/B of the stepped loop (harness build only)
         if constexpr (MODE == SPMV_AX || MODE == SPMV_AX_DOT) {
             if (std::getenv("SNS_FP64_STEPPED")) {
                 hipLaunchKernelGGL((k_spmv<MODE, 1, 3, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
-                                   x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                                   x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0, GhostSrc());
                 time_end(h);
                 return;
             }
         }
 #endif
         hipLaunchKernelGGL((k_spmv<MODE, 1, 1, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
-                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0, GhostSrc());
         time_end(h);
     } else if constexpr (MODE != SPMV_AX_DOT) {
         hipLaunchKernelGGL((k_spmv<MODE, 0, 0, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, L.vals,
-                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0);
+                           x, y, b, L.dinv, omega, dotw, h->partial, (const int32_t*)nullptr, (const uint8_t*)nullptr, 0, GhostSrc());
     }
 }
 
@@ -341,7 +357,7 @@ void launch_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, doub
 // (amg_f32_matrix: 1 = fp32, 2 = fp16 with row scales).
 template <int MODE, int FINE, int SPLIT, int FMT>
 void launch_lp(sns_ctx* h, const Level& L, int32_t rows, hipStream_t st, const double* x, double* y, const double* b,
-               double omega) {
+               double omega, const GhostSrc& gs = GhostSrc()) {
     const int grid = (rows + 63) / 64;
     if (grid == 0) return;
     const void* vals = FMT == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
@@ -349,14 +365,14 @@ void launch_lp(sns_ctx* h, const Level& L, int32_t rows, hipStream_t st, const d
     if constexpr (FMT == 2 && FINE == 1 && SPLIT == 0) {
         if (std::getenv("SNS_LP_STEPPED")) {
             hipLaunchKernelGGL((k_spmv_lp<MODE, 1, 0, 2, 0>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
-                               L.scale16, x, y, b, L.dinv32, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+                               L.scale16, x, y, b, L.dinv32, omega, (const int32_t*)nullptr, (const uint8_t*)nullptr, GhostSrc());
             return;
         }
     }
 #endif
     hipLaunchKernelGGL((k_spmv_lp<MODE, FINE, SPLIT, FMT, 1>), dim3(grid), dim3(256), 0, st, rows, L.rowptr, L.colind, vals,
                        L.scale16, x, y, b, L.dinv32, omega, SPLIT == 2 ? h->bnd_rows : (const int32_t*)nullptr,
-                       SPLIT == 1 ? h->bnd_flag : (const uint8_t*)nullptr);
+                       SPLIT == 1 ? h->bnd_flag : (const uint8_t*)nullptr, gs);
 }
 template <int MODE, int FMT>
 void launch_lp_fmt(sns_ctx* h, const Level& L, int32_t rows, const double* x, double* y, const double* b, double omega,
@@ -369,6 +385,10 @@ void launch_lp_fmt(sns_ctx* h, const Level& L, int32_t rows, const double* x, do
         time_end(h, st);
     } else if (fine && sp.mode == 2) {
         launch_lp<MODE, 1, 2, FMT>(h, L, h->n_bnd, st, x, y, b, omega);
+    } else if (fine && sp.mode == 3) {
+        time_begin(h, MODE, st);
+        launch_lp<MODE, 1, 3, FMT>(h, L, rows, st, x, y, b, omega, sp.gs);
+        time_end(h, st);
     } else if (fine) {
         time_begin(h, MODE);
         launch_lp<MODE, 1, 0, FMT>(h, L, rows, st, x, y, b, omega);
@@ -391,6 +411,12 @@ void launch_pc_spmv(sns_ctx* h, const Level& L, int32_t rows, const double* x, d
     else launch_spmv<MODE>(h, L, rows, x, y, b, omega, nullptr, sp);
 }
 
+// Do the level-0 passes of this handle read their ghost entries straight from the receive window (halo_windows)?
+inline bool fine_windows(const sns_ctx* h) {
+    const Comm* c = h->comm.get();
+    return c && c->windows() && c->nranks > 1 && h->opt.halo_windows && !h->team_overlap && !c->plans.empty() &&
+           c->plans[0].identity_recv && c->plans[0].win_recv[0] != nullptr;
+}
 // Level-0 pass whose input needs a halo exchange first (multi-GPU): the exchange of xe's ghost tail runs on the
 // handle's stream (every RCCL call stays on ONE stream, in program order) while the interior rows -- the rows
 // without a ghost column, i.e. nearly all of them -- are computed on a second stream; the few boundary rows follow
@@ -410,6 +436,17 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         }
         launch_spmv<MODE>(h, L, rows, x, y, b, omega, dotw, sp);
     };
+    if (dist && fine_windows(h) && xe == x) {
+        // window transports: ONE put launch; the pass reads the ghost entries from the receive window and its boundary waves
+        // wait for the neighbours' flags themselves -- no unpack, no boundary launch, no second stream
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, c->plans[0], xe, h->stream));
+        Split s3;
+        s3.mode = 3;
+        s3.gs = comm_ghost_src(c, c->plans[0]);
+        pass(s3);
+        return SNS_OK;
+    }
     if (!dist || !h->bnd_flag || h->no_overlap || !h->opt.halo_overlap) {
         SNS_TRY(halo_exchange(h, xe));
         pass(Split());
@@ -421,7 +458,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
     s2.mode = 2;
     s2.partial_off = gs;
     if (MODE == SPMV_AX_DOT) h->bnd_dot_blocks = (h->n_bnd + 31) / 32;
-    if (c->nccl || c->peer || h->team_overlap) {
+    if (c->nccl || (c->peer && !c->team) || h->team_overlap) {
         // (team transport with SNS_TEAM_OVERLAP=1: the same two-stream choreography -- interior pass on the side
         // stream, event joins, per-launch timing events on that stream -- over the emulated exchange, so that the
         // stream dependencies of the production path are exercised on a 1-GPU box)
@@ -550,7 +587,7 @@ int connect_plan(sns_ctx* h, Plan& p) {
     if (!c || !c->peer) return SNS_OK;
     PlanOffers t;
     const int rc = peer_plan_offer(c, p, t);
-    if (rc != SNS_OK) t.mine.assign((size_t)3 * c->nranks, -2.0);      // (still take part in the all-gather: the peers must not hang)
+    if (rc != SNS_OK) t.mine.assign((size_t)3 * c->nranks + 1, -2.0);  // (still take part in the all-gather: the peers must not hang)
     SNS_TRY(host_allgather(h, t.mine, t.all));
     if (rc != SNS_OK) return rc;
     for (double v : t.all)
@@ -636,11 +673,11 @@ void launch_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double*
         const unsigned grid = (unsigned)((ns + 63) / 64);
         if (grid == 0) return;
         if (L.binv_fmt == 2)
-            hipLaunchKernelGGL((k_bsweep<2>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega);
+            hipLaunchKernelGGL((k_bsweep<2, 0>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                               (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, GhostSrc());
         else
-            hipLaunchKernelGGL((k_bsweep<1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega);
+            hipLaunchKernelGGL((k_bsweep<1, 0>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                               (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, GhostSrc());
         return;
     }
     launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x, y, b, omega);
@@ -790,6 +827,29 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
     h->rep_maxnz = maxnz;
     h->rep_NG = NG;
     h->rep_off = (int32_t)off[me];
+    {
+        // window transports: the right-hand sides go straight to their rows of the replicated level (comm_allgatherv) ...
+        std::vector<int64_t> doff((size_t)nr), dcnt((size_t)nr);
+        for (int r = 0; r < nr; ++r) { doff[(size_t)r] = 4 * off[r]; dcnt[(size_t)r] = 4 * (int64_t)cnt[r]; }
+        SNS_TRY(dev_upload(&h->rep_doff, doff, h->stream));
+        SNS_TRY(dev_upload(&h->rep_dcnt, dcnt, h->stream));
+        // ... and the level above the source reads the coarse solution of its fused correction + post-sweep straight from the
+        // replicated solution: the columns of its M = A P (local ids of level R: owned, then ghosts) in the replicated level's ids
+        Level& A = h->levels[R - 1];
+        if (R >= 2 && A.ap_colind && A.ap_nnz > 0) {
+            std::vector<int32_t> col((size_t)A.ap_nnz);
+            HIP_TRY(hipMemcpy(col.data(), A.ap_colind, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (auto& j : col) {
+                if (j < n_owned) j = (int32_t)off[me] + j;
+                else {
+                    const size_t q = (size_t)(j - n_owned);
+                    if (q >= g_own.size()) { set_error("replicated tail: ghost aggregate without an owner record"); return SNS_E_STATE; }
+                    j = (int32_t)off[g_own[q]] + g_gid[q];
+                }
+            }
+            SNS_TRY(dev_upload(&A.ap_colind_rep, col, h->stream));
+        }
+    }
     SNS_TRY(append_level(h, G, NG, false));
     h->ghost_own.emplace_back();
     h->ghost_gid.emplace_back();
@@ -893,6 +953,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
             HIP_TRY(hipMemcpy(ids.data(), L.xg, ids.size() * sizeof(double), hipMemcpyDeviceToHost));
             HIP_TRY(hipMemset(L.xg, 0, ids.size() * sizeof(double)));
             cplan.nbr = p.nbr;
+            cplan.n_own = nc_owned;
             cplan.send_ptr.assign(1, 0);
             cplan.recv_ptr.assign(1, 0);
             for (size_t k = 0; k < p.nbr.size(); ++k) {
@@ -935,7 +996,8 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         SNS_TRY(upload_block_rows(h, l, L, A.m_ptr, A.m_idx, nc_owned));
         // M = A P for the fused first post-smoothing sweep: every level of a serial hierarchy; in a partitioned one the fine
         // level only (its single post-sweep is the exact global sweep; the distributed coarse levels smooth rank-locally)
-        if (!dist || l == 0) SNS_TRY(upload_ap(h, L, cur, n_owned, A.agg));
+        // ... and, on the window transports, every partitioned level: the exact-sweep cycle (level_exact) takes the fused post-sweep too
+        if (!dist || l == 0 || c->windows()) SNS_TRY(upload_ap(h, L, cur, n_owned, A.agg));
         h->levels.emplace_back();
         h->slot_row.push_back(nullptr);
         h->empty_c.push_back(nullptr);
@@ -1239,7 +1301,26 @@ inline int level_nu(const sns_ctx* h, int l) {
 inline bool level_px(const sns_ctx* h, int l, const Level& L) {
     return L.xg && !level_sx(h, L) && h->opt.amg_post_exchange && level_nu(h, l) == 1 && (l == 0 || !block_active(h, l));
 }
-inline bool uses_ghosts_in_sweeps(const sns_ctx* h, int l, const Level& L) { return level_sx(h, L) || level_px(h, l, L); }
+// Partitioned level l >= 1 cycled with EXACT global sweeps over a window transport (amg_exact_sweeps, round 5): every sweep is
+// preceded by one put launch and reads its ghost entries from the receive window, the coarse-grid correction sits inside the
+// first post-sweep (M = A P), residual + restriction stay one launch -- the single-GPU cycle, distributed.  Options and the
+// hierarchy's global structure only: every rank answers alike.
+inline bool level_exact(const sns_ctx* h, int l) {
+    const Comm* c = h->comm.get();
+    if (!c || !c->windows() || c->nranks <= 1 || !h->opt.halo_windows || !h->opt.amg_exact_sweeps || h->team_overlap) return false;
+    if (l < 1 || l + 1 >= (int)h->levels.size() || (size_t)l >= c->plans.size()) return false;
+    const Level& L = h->levels[l];
+    if (!L.xg || (h->rep_level > 0 && l >= h->rep_level - 1)) return false;     // partitioned AND cycled (not the replicated tail's source)
+    if (level_sx(h, L) || !block_active(h, l) || !L.ap_rowptr) return false;
+    if (!h->opt.amg_fused_post || h->opt.amg_fuse_restrict == 0 || h->opt.pc_type != SNS_PC_AMG) return false;
+    if (!c->plans[l].identity_recv || !c->plans[l].win_recv[0]) return false;
+    const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
+    if (rep_src) return L.ap_colind_rep != nullptr;                             // xc straight from the replicated solution
+    return (size_t)(l + 1) < c->plans.size() && c->plans[l + 1].identity_recv && c->plans[l + 1].win_recv[0] != nullptr;
+}
+inline bool uses_ghosts_in_sweeps(const sns_ctx* h, int l, const Level& L) {
+    return level_sx(h, L) || level_px(h, l, L) || level_exact(h, l);
+}
 int estimate_lambda_max(sns_ctx* h, int l, double* out) {
     Level& L = h->levels[l];
     const int32_t rows = L.n_owned;
@@ -1301,10 +1382,17 @@ int arnoldi_ritz(sns_ctx* h, int l, double* theta_max, double* limit) {
     const int64_t nd = 4 * (int64_t)rows;
     *theta_max = 0.0;
     *limit = 1e30;
-    if (rows <= 0) return SNS_OK;
-    const int g = vec_grid(nd);
-    const bool glob = uses_ghosts_in_sweeps(h, l, L);
-    if (glob) return SNS_OK;                           // (sweeps that see exchanged ghost values: not estimated here)
+    // levels whose sweeps see exchanged ghost values (level_exact): the GLOBAL operator's Ritz values -- one exchange per Arnoldi
+    // step, the dots summed over the ranks; collective, so every rank goes through it whatever its row count.  (Levels that
+    // exchange per sweep by amg_sweep_exchange_rows / the fine level's single post-sweep: not estimated, as in round 4.)
+    const bool glob = level_exact(h, l);
+    if (!glob && (rows <= 0 || uses_ghosts_in_sweeps(h, l, L))) return SNS_OK;
+    const int g = std::max(1, vec_grid(nd));           // (a rank without rows on a collective level still launches: empty loops, zero partials)
+    auto reduce = [&](int nred, double* dst) -> int {
+        if (glob) return reduce_to(h, g, nred, dst);
+        reduce_local(h, g, nred, dst);
+        return SNS_OK;
+    };
     if (h->arn_cap < (size_t)(M + 1) * nd) {
         if (h->arn_V) (void)hipFree(h->arn_V);
         h->arn_V = nullptr;
@@ -1322,7 +1410,7 @@ int arnoldi_ritz(sns_ctx* h, int l, double* theta_max, double* limit) {
     double* sc = h->d_scal + 192;                      // [0, 8) pass-1 coefficients, [8, 16) pass 2, [16, 18) (w.w, w.w)
     hipLaunchKernelGGL(k_fill_pattern, dim3(g), dim3(256), 0, h->stream, nd, V);
     hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, V, V, h->partial);
-    reduce_local(h, g, 2, sc + 16);
+    SNS_TRY(reduce(2, sc + 16));
     hipLaunchKernelGGL(k_scale_by_rsqrt, dim3(g), dim3(256), 0, h->stream, nd, sc + 17, V, V);
     std::vector<double> H((size_t)M * M, 0.0);
     const bool lp = lp_format(h, L) != 0;
@@ -1331,18 +1419,19 @@ int arnoldi_ritz(sns_ctx* h, int l, double* theta_max, double* limit) {
         double* vj = V + (size_t)j * nd;
         double* w = V + (size_t)(j + 1) * nd;
         HIP_TRY(hipMemcpyAsync(xin, vj, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (glob) SNS_TRY(exchange_level(h, l, xin));
         // y = -A~ v (the copy the sweeps read) resp. + A v; w = S A v
         if (lp) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, xin, y, zero, 0.0);
         else launch_spmv<SPMV_AX>(h, L, rows, xin, y, nullptr, 0.0, nullptr);
         launch_first_sweep(h, l, L, rows, y, lp ? -1.0 : 1.0, w);
         for (int pass = 0; pass < 2; ++pass) {
             hipLaunchKernelGGL(k_multi_dot8, dim3(g), dim3(256), 0, h->stream, nd, j + 1, V, nd, w, h->partial);
-            reduce_local(h, g, 8, sc + 8 * pass);
+            SNS_TRY(reduce(8, sc + 8 * pass));
             hipLaunchKernelGGL(k_multi_axpy8, dim3(g), dim3(256), 0, h->stream, nd, j + 1, V, nd, sc + 8 * pass, -1.0, w,
                                (double*)nullptr);
         }
         hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->stream, nd, w, w, h->partial);
-        reduce_local(h, g, 2, sc + 16);
+        SNS_TRY(reduce(2, sc + 16));
         double v[18];
         SNS_TRY(fetch(h, sc, 18, v));
         for (int k = 0; k <= j; ++k) H[(size_t)k * M + j] = v[k] + v[8 + k];
@@ -1516,7 +1605,7 @@ int pc_setup(sns_ctx* h) {
                 int a = 1, b = 1;
                 level_sweeps(h, l, a, b);
                 if (a + b >= 3) {
-                    if (fresh && rows > 0) {
+                    if (fresh && (rows > 0 || level_exact(h, l))) {
                         double tmax = 0.0, lim = 1e30;
                         SNS_TRY(arnoldi_ritz(h, l, &tmax, &lim));
                         L.ritz_limit = lim;
@@ -1614,6 +1703,7 @@ int pc_setup(sns_ctx* h) {
     h->est_re = h->opt.reynolds;
     const bool check_sing = nl > 1 && (h->levels[nl - 1].dense_gj != nullptr || any_block);
     int* h_sing = reinterpret_cast<int*>(h->h_scal + 768);
+    *h_sing = 0;
     if (check_sing) HIP_TRY(hipMemcpyAsync(h_sing, h->d_sing, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1621,13 +1711,20 @@ int pc_setup(sns_ctx* h) {
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->tm.pc_setup_ms += ms;
     HIP_TRY(hipGetLastError());
-    if (check_sing && *h_sing != 0) {
-        // (the elimination runs without pivoting across its 64 x 64 blocks: see csrc/sns_dense.hip for why that is safe on this
-        // operator class; if it ever is not, say so instead of preconditioning with garbage)
-        HIP_TRY(hipMemset(h->d_sing, 0, sizeof(int)));
-        set_error("AMG setup: a dense inverse (coarsest level or an aggregate block) met a zero or non-finite pivot; set "
-                  "amg_dense_rows = 0 / amg_block_smooth = 0");
-        return SNS_E_STATE;
+    if (check_sing) {
+        // The aggregate blocks' inverses are rank-local: one rank alone returning an error here would leave the others in the
+        // Krylov loop's collectives (an RCCL hang, a peer time-out).  The verdict is taken over all ranks.
+        double bad[1] = {*h_sing != 0 ? 1.0 : 0.0};
+        SNS_TRY(global_sum(h, bad, 1));
+        if (bad[0] != 0.0) {
+            // (the elimination runs without pivoting across its 64 x 64 blocks: see csrc/sns_dense.hip for why that is safe on this
+            // operator class; if it ever is not, say so instead of preconditioning with garbage -- there is no fallback hierarchy)
+            HIP_TRY(hipMemset(h->d_sing, 0, sizeof(int)));
+            set_error("AMG setup: a dense inverse (coarsest level or an aggregate block" +
+                      std::string(*h_sing != 0 ? "" : ", on another rank") + ") met a zero or non-finite pivot; set "
+                      "amg_dense_rows = 0 / amg_block_smooth = 0");
+            return SNS_E_STATE;
+        }
     }
     h->pc_ready = true;
     return SNS_OK;
@@ -1644,7 +1741,8 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
         // needs the iterations of 4 + 4 with one level-1 pass less (-3 % per Newton step on the 10 M-tet duct, neutral
         // elsewhere); a partitioned handle keeps nu + nu, its post-sweeps being rank-local (1 + 6 costs 8-11 % more
         // iterations there)
-        const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1;
+        // (... unless its sweeps are the exact global ones: level_exact -- then it IS the single-GPU cycle)
+        const bool partitioned = h->comm && h->comm->active() && h->comm->nranks > 1 && !level_exact(h, l);
         if (block_active(h, l)) {
             if (!partitioned) { nu_pre = 1; nu_post = std::max(1, h->opt.amg_bnu_l1); }
         } else if (h->opt.amg_nu_l1_pre == 0 && h->opt.amg_nu_l1_post == 0 && !partitioned && nu >= 2) {
@@ -1772,6 +1870,152 @@ int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
     return SNS_OK;
 }
 
+// one aggregate-block sweep of a partitioned level with the ghost entries of x from the level's receive window
+void launch_sweep_windows(sns_ctx* h, const Level& L, const double* x, double* y, const double* b, double omega, const GhostSrc& gs) {
+    const int32_t ns = 8 * L.n_blk;
+    const unsigned grid = (unsigned)((ns + 63) / 64);
+    if (grid == 0) return;
+    if (L.binv_fmt == 2)
+        hipLaunchKernelGGL((k_bsweep<2, 1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                           (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, gs);
+    else
+        hipLaunchKernelGGL((k_bsweep<1, 1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
+                           (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, gs);
+}
+
+// Does level l run the window form of the cycle (vcycle_windows)?  The fine level: its passes read the receive window and its
+// single post-sweep is the fused exact one; a level >= 1: level_exact.
+inline bool level_windows(const sns_ctx* h, int l) {
+    if (l == 0) {
+        const Comm* c = h->comm.get();
+        return fine_windows(h) && fine_tails_unused(h) && c->plans.size() > 1 && c->plans[1].identity_recv &&
+               c->plans[1].win_recv[0] != nullptr;
+    }
+    return level_exact(h, l);
+}
+
+// The V-cycle of a PARTITIONED level over a window transport (peer windows / the in-process team; round 5).  Every exchange is one
+// put launch (comm_put) and the pass behind it reads the ghost entries from the level's receive window, its boundary waves waiting
+// for the neighbours themselves: no staging copy, no unpack, no split pass.  Level 0: first sweep | put, residual | restriction
+// (+ level 1's first sweep) | coarse | put of level 1's solution, fused correction + post-sweep.  Level >= 1 (level_exact): the
+// single-GPU schedule with exact global sweeps -- [put, sweep]* | put, residual + restriction (+ next first sweep) in one launch |
+// coarse | fused correction + first post-sweep (the coarse solution read straight from the replicated tail where that is the next
+// level, else after a put of it) | [put, sweep]*.
+int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
+    Level& L = h->levels[l];
+    Level& C = h->levels[l + 1];
+    Comm* c = h->comm.get();
+    const Plan& P = c->plans[l];
+    const int32_t rows = L.n_owned;
+    const double om = L.omega;
+    int nu_pre = 1, nu_post = 1;
+    level_sweeps(h, l, nu_pre, nu_post);
+    double* cur = cycle_start_buffer(h, l, x);
+    double* oth = (cur == x) ? h->pong[l] : x;
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1)) && !(l == 0 && h->first_sweep_done))
+        launch_first_sweep(h, l, L, rows, b, om, cur);
+    if (l == 0) h->first_sweep_done = false;
+    for (int s = 1; s < nu_pre; ++s) {                     // (level >= 1 only: the fine level runs one sweep per half cycle)
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, P, cur, h->stream));
+        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        std::swap(cur, oth);
+    }
+    const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
+    double* cb = rep_src ? h->rep_bsend : C.b;
+    const double* cx = rep_src ? h->levels[h->rep_level].x + 4 * (size_t)h->rep_off : C.x;
+    const bool fuse = restrict_fuses_first(h, l);
+    const float* dc = fuse ? C.dinv32 : nullptr;
+    double* zc = fuse ? cycle_start_buffer(h, l + 1, C.x) : nullptr;
+    const int fmt = lp_format(h, L);
+    // residual (+ restriction): the true residual needs the neighbours' iterate
+    ++h->ctr_exchange;
+    SNS_TRY(comm_put(c, P, cur, h->stream));
+    const GhostSrc gs = comm_ghost_src(c, P);
+    if (l == 0) {
+        Split s3;
+        s3.mode = 3;
+        s3.gs = gs;
+        if (rows > 0) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, s3);
+        if (C.n_owned > 0) {
+            if (fuse && block_active(h, 1)) {
+                const int32_t ns = 8 * C.n_blk;
+                if (C.binv_fmt == 2)
+                    hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                else
+                    hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+            } else {
+                hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                                   C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
+            }
+        }
+    } else if (rows > 0 && C.n_owned > 0) {
+        const int mode = !fuse ? 0 : (block_active(h, l + 1) ? 2 : 1);
+        const int32_t* slots = mode == 2 ? C.blk_rows : nullptr;
+        const int32_t n_slots = mode == 2 ? 8 * C.n_blk : C.n_owned;
+        const unsigned grid = (unsigned)((n_slots + 7) / 8);
+        const void* vals = fmt == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
+        const float* sc16 = fmt == 2 ? L.scale16 : nullptr;
+#define SNS_RRW(F, M)                                                                                                              \
+    hipLaunchKernelGGL((k_resid_restrict<F, M, 1>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, (const double*)cur, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, gs)
+        if (fmt == 2) { if (mode == 2) SNS_RRW(2, 2); else if (mode == 1) SNS_RRW(2, 1); else SNS_RRW(2, 0); }
+        else          { if (mode == 2) SNS_RRW(1, 2); else if (mode == 1) SNS_RRW(1, 1); else SNS_RRW(1, 0); }
+#undef SNS_RRW
+    }
+    SNS_TRY(coarse_cycle(h, l + 1, cb, rep_src ? nullptr : C.x));
+    // fused coarse-grid correction + first post-smoothing sweep over M = A P; the ghost aggregates' part of the coarse solution:
+    // level >= 1 above the replicated tail reads every entry from the replicated solution (M's columns renumbered into its ids,
+    // ap_colind_rep), else one put of the coarse level's solution and the window behind it
+    GhostSrc gc;
+    const double* xc = cx;
+    const int32_t* apc = L.ap_colind;
+    if (rep_src && l >= 1) {
+        xc = h->levels[h->rep_level].x;
+        apc = L.ap_colind_rep;
+    } else {
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, c->plans[l + 1], cx, h->stream));
+        gc = comm_ghost_src(c, c->plans[l + 1]);
+    }
+    if (rows > 0) {
+        if (l == 0) time_begin(h, 4);
+        if (block_active(h, l) && L.binv32) {
+            const int32_t ns = 8 * L.n_blk;
+            const unsigned gb = (unsigned)((ns + 63) / 64);
+            const void* mv = fmt == 2 ? (const void*)L.ap_vals16 : (const void*)L.ap_vals32;
+            const float* ms = fmt == 2 ? L.ap_scale16 : nullptr;
+#define SNS_BPW(F, G)                                                                                                          \
+    hipLaunchKernelGGL((k_bpost<F, G>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, apc, mv, ms,             \
+                       (const void*)L.binv32, xc, cx, (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, gc)
+            if (gc.win[0]) { if (fmt == 2) SNS_BPW(2, 1); else SNS_BPW(1, 1); }
+            else           { if (fmt == 2) SNS_BPW(2, 0); else SNS_BPW(1, 0); }
+#undef SNS_BPW
+        } else {
+            const int grid = (rows + 63) / 64;             // (nodal blocks: the fine level only, see level_exact)
+            if (fmt == 2)
+                hipLaunchKernelGGL((k_post_lp<2, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_vals16,
+                                   L.ap_scale16, xc, (const double*)cur, (const double*)L.r, L.dinv32, om, L.agg, L.free_mask, oth, gc);
+            else
+                hipLaunchKernelGGL((k_post_lp<1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                   (const void*)L.ap_vals32, (const float*)nullptr, xc, (const double*)cur, (const double*)L.r, L.dinv32,
+                                   om, L.agg, L.free_mask, oth, gc);
+        }
+        if (l == 0) time_end(h);
+    }
+    std::swap(cur, oth);
+    for (int s = 1; s < nu_post; ++s) {
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, P, cur, h->stream));
+        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        std::swap(cur, oth);
+    }
+    // cur == x by construction of the start buffer
+    return SNS_OK;
+}
+
 // V-cycle on level l: x <- approx A_l^-1 b  (x overwritten; zero initial guess)
 int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     Level& L = h->levels[l];
@@ -1784,9 +2028,16 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         Level& C = h->levels[h->rep_level];
         if (rows > 0 && b != h->rep_bsend)                   // (vcycle of the level above restricts straight into rep_bsend)
             HIP_TRY(hipMemcpyAsync(h->rep_bsend, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        SNS_TRY(comm_allgather(h->comm.get(), h->rep_bsend, h->rep_brecv, 4 * h->rep_maxn, h->stream));
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((4 * (int64_t)h->rep_NG + 255) / 256)), dim3(256), 0, h->stream,
-                           h->rep_NG, h->rep_rowmap, h->rep_brecv, C.b);
+        Comm* cm = h->comm.get();
+        if (cm->windows() && h->opt.halo_windows && h->rep_doff &&
+            (size_t)4 * h->rep_maxn * (size_t)cm->nranks <= cm->peer->ag_doubles) {
+            // (every rank's rows land where the replicated level keeps them: no gather kernel behind the all-gather)
+            SNS_TRY(comm_allgatherv(cm, h->rep_bsend, C.b, 4 * h->rep_maxn, h->rep_doff, h->rep_dcnt, h->stream));
+        } else {
+            SNS_TRY(comm_allgather(cm, h->rep_bsend, h->rep_brecv, 4 * h->rep_maxn, h->stream));
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((4 * (int64_t)h->rep_NG + 255) / 256)), dim3(256), 0, h->stream,
+                               h->rep_NG, h->rep_rowmap, h->rep_brecv, C.b);
+        }
         SNS_TRY(coarse_cycle(h, h->rep_level, C.b, C.x));
         if (rows > 0 && x)                                   // (x == nullptr: the caller reads its rows of C.x in place)
             HIP_TRY(hipMemcpyAsync(x, C.x + 4 * (size_t)h->rep_off, 4 * (size_t)rows * sizeof(double),
@@ -1827,6 +2078,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
         }
         return SNS_OK;
     }
+    if (level_windows(h, l)) return vcycle_windows(h, l, b, x);
     if (l == 0 && !L.xg && h->opt.amg_fine_cycle != 0 && rows > 0) {
         // experimental fine-level cycle shapes (single GPU): 1 = V(0,1): no pre-smoothing, the right-hand side itself
         // is restricted; 2 = V(1,0): no post-smoothing.  One fine-level matrix pass per cycle instead of two.
@@ -1926,8 +2178,8 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             const void* vals = fmt_rr == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
             const float* sc16 = fmt_rr == 2 ? L.scale16 : nullptr;
 #define SNS_RR(F, M)                                                                                                            \
-    hipLaunchKernelGGL((k_resid_restrict<F, M>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
-                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc)
+    hipLaunchKernelGGL((k_resid_restrict<F, M, 0>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, GhostSrc())
             if (l == 0) time_begin(h, SPMV_B_MINUS_AX);                      // (bench.py's per-launch accounting of the fine-level passes)
             if (fmt_rr == 2) { if (mode == 2) SNS_RR(2, 2); else if (mode == 1) SNS_RR(2, 1); else SNS_RR(2, 0); }
             else             { if (mode == 2) SNS_RR(1, 2); else if (mode == 1) SNS_RR(1, 1); else SNS_RR(1, 0); }
@@ -1971,29 +2223,29 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
                 const int32_t ns = 8 * L.n_blk;
                 const unsigned gb = (unsigned)((ns + 63) / 64);
                 if (fmt_l == 2)
-                    hipLaunchKernelGGL((k_bpost<2>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
-                                       (const void*)L.ap_vals16, L.ap_scale16, (const void*)L.binv32, xc, cur, L.r, om, L.agg,
-                                       L.free_mask, oth);
+                    hipLaunchKernelGGL((k_bpost<2, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals16, L.ap_scale16, (const void*)L.binv32, xc, xc, (const double*)cur,
+                                       (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
                 else
-                    hipLaunchKernelGGL((k_bpost<1>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
-                                       (const void*)L.ap_vals32, (const float*)nullptr, (const void*)L.binv32, xc, cur, L.r, om,
-                                       L.agg, L.free_mask, oth);
+                    hipLaunchKernelGGL((k_bpost<1, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, (const void*)L.binv32, xc, xc,
+                                       (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
             } else if (fmt_l == 2) {
                 if (fine)
                     hipLaunchKernelGGL((k_post_lp<2, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
-                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth);
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth, GhostSrc());
                 else
                     hipLaunchKernelGGL((k_post_lp<2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
-                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth);
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth, GhostSrc());
             } else {
                 if (fine)
                     hipLaunchKernelGGL((k_post_lp<1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
                                        (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
-                                       L.free_mask, oth);
+                                       L.free_mask, oth, GhostSrc());
                 else
                     hipLaunchKernelGGL((k_post_lp<1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
                                        (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
-                                       L.free_mask, oth);
+                                       L.free_mask, oth, GhostSrc());
             }
             if (fine) time_end(h);
         }
@@ -2025,7 +2277,14 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
     return SNS_OK;
 }
 
+int pc_apply_inner(sns_ctx* h, const double* r, double* z);
+// (first_sweep_done is consumed by the cycle this call runs and by nothing else: cleared on every way out)
 int pc_apply(sns_ctx* h, const double* r, double* z) {
+    const int rc = pc_apply_inner(h, r, z);
+    h->first_sweep_done = false;
+    return rc;
+}
+int pc_apply_inner(sns_ctx* h, const double* r, double* z) {
     const int64_t nd = nred_of(h);
     switch (h->opt.pc_type) {
         case SNS_PC_NONE:
@@ -2457,6 +2716,7 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
 int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double* rnorm) {
     if (!h->has_matrix) { set_error("krylov_solve before a matrix was assembled"); return SNS_E_STATE; }
     if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
+    h->first_sweep_done = false;                 // (a solve that ended in an error between setting and consuming it must not leak it)
     h->ctr_host_syncs = h->ctr_allreduce = h->ctr_exchange = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // A solve that BREAKS DOWN (or produces NaN/Inf) under the AMG preconditioner is retried ONCE, from the same initial
@@ -2581,6 +2841,8 @@ void sns_default_options(sns_options* o) {
     o->amg_block_max_rows = 0;
     o->amg_block_fine_rows = 600000;
     o->amg_fuse_restrict = 1;
+    o->halo_windows = 1;
+    o->amg_exact_sweeps = 1;
 }
 
 const char* sns_last_error(void) { return g_err.c_str(); }
@@ -2760,14 +3022,14 @@ int sns_destroy(sns_handle h) {
     for (auto& L : h->levels) {
         fr(L.rowptr); fr(L.colind); fr(L.diag); fr(L.vals); fr(L.dinv); fr(L.agg); fr(L.m_ptr); fr(L.m_idx);
         fr(L.r_ptr); fr(L.r_idx); fr(L.free_mask); fr(L.x); fr(L.b); fr(L.r); fr(L.dense_inv); fr(L.dense_gj); fr(L.dense_work); fr(L.dense_x32); fr(L.vals32); fr(L.vals16); fr(L.scale16); fr(L.dinv32);
-        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16); fr(L.blk_rows); fr(L.blk_of); fr(L.binv32);
+        fr(L.ap_rowptr); fr(L.ap_colind); fr(L.ap_colind_rep); fr(L.ap_ptr); fr(L.ap_idx); fr(L.ap_nib); fr(L.ap_vals32); fr(L.ap_vals16); fr(L.ap_scale16); fr(L.blk_rows); fr(L.blk_of); fr(L.binv32);
     }
     for (auto p : h->slot_row) fr(p);
     for (auto p : h->empty_c) fr(p);
     for (auto p : h->pong) fr(p);
     for (auto p : h->kv) fr(p);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
-    fr(h->d_piv); fr(h->d_sing); fr(h->rep_valmap); fr(h->rep_rowmap); fr(h->rep_vsend); fr(h->rep_vrecv); fr(h->rep_bsend); fr(h->rep_brecv);
+    fr(h->d_piv); fr(h->d_sing); fr(h->rep_valmap); fr(h->rep_rowmap); fr(h->rep_vsend); fr(h->rep_vrecv); fr(h->rep_bsend); fr(h->rep_brecv); fr(h->rep_doff); fr(h->rep_dcnt);
     fr(h->arn_V);
     fr(h->partial); fr(h->partial2); fr(h->d_scal); fr(h->gm_V); fr(h->gm_Z); fr(h->d_h);
     fr(h->nw_F); fr(h->nw_y); fr(h->nw_w); fr(h->nw_t);
@@ -2868,6 +3130,7 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     c.nranks = nranks;
     c.team = team;
     c.peer = peer;
+    if (team) SNS_TRY(team_peer(team, h->device, rank, &c.peer));      // (the team runs the peer transport's kernels, sns_comm.h)
     if (uid) {
         ncclUniqueId id;
         std::memcpy(&id, uid, 128);
@@ -2877,6 +3140,7 @@ static int attach_common(sns_handle h, int rank, int nranks, const char* uid, Te
     h->levels[0].n_owned = n_owned;
     c.plans.emplace_back();
     Plan& p = c.plans[0];
+    p.n_own = n_owned;
     p.nbr.assign(nbr, nbr + n_nbr);
     if (n_nbr > 0) {
         p.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);

@@ -58,9 +58,12 @@ __device__ __forceinline__ double lp_dot_b(const f16x4_t a, const double2 xa, co
 // sum_k A_rk x_k for dof row r (= lane & 3) of the block row [s, e) of a low-precision level matrix (FMT 1: fp32 blocks, FMT 2:
 // fp16 pair-interleaved blocks; the row scale of FMT 2 is applied by the caller).  The stepped loop of k_spmv_lp: one index load
 // per quad and step of 4 blocks (requested one step ahead), the x gather as whole blocks handed round by DPP.  s, e are quad-uniform.
-template <int FMT>
+// GH: the ghost columns' x blocks come from the level's receive window (window transports: GhostSrc / GhostReader, sns_peer_dev.h);
+// the wave that meets the first ghost column waits for the neighbours' arrival flags.
+template <int FMT, int GH = 0>
 __device__ __forceinline__ double lp_row_times_x(int32_t s, int32_t e, const int32_t* __restrict__ colind,
-                                                 const void* __restrict__ vals_v, const double* __restrict__ x, int r) {
+                                                 const void* __restrict__ vals_v, const double* __restrict__ x, int r,
+                                                 GhostReader* gr = nullptr, const GhostSrc* gs = nullptr) {
     double acc0 = 0.0, acc1 = 0.0;
     const float4* __restrict__ v32 = reinterpret_cast<const float4*>(vals_v) + ((int64_t)s * 4 + r);
     const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vals_v) + ((int64_t)s * 2 + r);
@@ -69,7 +72,8 @@ __device__ __forceinline__ double lp_row_times_x(int32_t s, int32_t e, const int
     for (; k + 3 < e; k += 4) {
         const int32_t cme = cnext;
         if (k + 7 < e) cnext = colind[k + 4 + r];
-        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        if (GH) gr->arrive(*gs, cme >= gr->n_own);
+        const double2* xp = reinterpret_cast<const double2*>(GH ? gr->ptr(x, cme) : x + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];
         if (FMT == 1) {
             const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
@@ -91,7 +95,8 @@ __device__ __forceinline__ double lp_row_times_x(int32_t s, int32_t e, const int
     if (k < e) {                                                  // 1..3 blocks left; quad-uniform
         const int32_t left = e - k;
         const int32_t cme = colind[k + (r < left ? r : 0)];
-        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        if (GH) gr->arrive(*gs, cme >= gr->n_own);
+        const double2* xp = reinterpret_cast<const double2*>(GH ? gr->ptr(x, cme) : x + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];
         if (FMT == 1) {
             acc0 += lp_dot_b(v32[0], qb2<0>(xa), qb2<0>(xb));
@@ -172,13 +177,15 @@ __device__ __forceinline__ double block_apply(const BinvRow<BF>& B, double res, 
 }  // namespace
 
 // one sweep  y = x + w B^-1 (b - A x)  over the aggregates' member rows; n_slots = 8 * number of aggregates
-template <int FMT>
+template <int FMT, int GH>
 __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* __restrict__ blk_rows,
                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                 const void* __restrict__ vals_v, const float* __restrict__ scale,
                                                 const void* __restrict__ binv, const double* __restrict__ x,
-                                                double* __restrict__ y, const double* __restrict__ bvec, double omega) {
+                                                double* __restrict__ y, const double* __restrict__ bvec, double omega, GhostSrc gs) {
     __shared__ double sres[8 * 32];
+    GhostReader gr;
+    if (GH) gr.begin(gs);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
     const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
@@ -193,26 +200,32 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
         pre_b = bvec[4 * (int64_t)row + r];
         pre_x = x[4 * (int64_t)row + r];
     }
-    const double acc = sc * lp_row_times_x<FMT>(s, e, colind, vals_v, x, r);
+    const double acc = sc * lp_row_times_x<FMT, GH>(s, e, colind, vals_v, x, r, &gr, &gs);
     const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
     if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
 }
-template __global__ void k_bsweep<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                     const void*, const double*, double*, const double*, double);
-template __global__ void k_bsweep<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                     const void*, const double*, double*, const double*, double);
+#define SNS_INST_BSWEEP(F, G)                                                                                                 \
+    template __global__ void k_bsweep<F, G>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*, \
+                                            const void*, const double*, double*, const double*, double, GhostSrc);
+SNS_INST_BSWEEP(1, 0) SNS_INST_BSWEEP(2, 0) SNS_INST_BSWEEP(1, 1) SNS_INST_BSWEEP(2, 1)
+#undef SNS_INST_BSWEEP
 
 // coarse-grid correction + first post-smoothing sweep over M = A P with the aggregate blocks (k_post_lp's algebra):
 //     y = (x1 + P xc) + w B^-1 (r1 - M xc)
-template <int FMT>
+// GH: xc's ghost aggregates from the coarse level's receive window.  xc_own: where the row's OWN aggregate I is read (the owned
+// part of the coarse vector; the same pointer as xc unless the columns of M were renumbered, e.g. into the replicated tail's ids)
+template <int FMT, int GH>
 __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* __restrict__ blk_rows,
                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                const void* __restrict__ vals_v, const float* __restrict__ scale,
                                                const void* __restrict__ binv, const double* __restrict__ xc,
+                                               const double* __restrict__ xc_own,
                                                const double* __restrict__ x_pre, const double* __restrict__ res1, double omega,
                                                const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
-                                               double* __restrict__ y) {
+                                               double* __restrict__ y, GhostSrc gs) {
     __shared__ double sres[8 * 32];
+    GhostReader gr;
+    if (GH) gr.begin(gs);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
     const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
@@ -227,18 +240,18 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
         if (FMT == 2) sc = (double)scale[4 * (int64_t)row + r];
         pre_b = res1[4 * (int64_t)row + r];
         pre_x = x_pre[4 * (int64_t)row + r];
-        if (I >= 0 && (!free_mask || free_mask[4 * (int64_t)row + r])) pre_x += xc[4 * (int64_t)I + r];   // (x1 + P xc)_row
+        if (I >= 0 && (!free_mask || free_mask[4 * (int64_t)row + r])) pre_x += xc_own[4 * (int64_t)I + r];   // (x1 + P xc)_row
     }
-    const double acc = sc * lp_row_times_x<FMT>(s, e, colind, vals_v, xc, r);
+    const double acc = sc * lp_row_times_x<FMT, GH>(s, e, colind, vals_v, xc, r, &gr, &gs);
     const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
     if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
 }
-template __global__ void k_bpost<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                    const void*, const double*, const double*, const double*, double, const int32_t*,
-                                    const uint8_t*, double*);
-template __global__ void k_bpost<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*,
-                                    const void*, const double*, const double*, const double*, double, const int32_t*,
-                                    const uint8_t*, double*);
+#define SNS_INST_BPOST(F, G)                                                                                                  \
+    template __global__ void k_bpost<F, G>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*, \
+                                           const void*, const double*, const double*, const double*, const double*, double,   \
+                                           const int32_t*, const uint8_t*, double*, GhostSrc);
+SNS_INST_BPOST(1, 0) SNS_INST_BPOST(2, 0) SNS_INST_BPOST(1, 1) SNS_INST_BPOST(2, 1)
+#undef SNS_INST_BPOST
 
 // z = w B^-1 b: the first sweep of a cycle (zero initial guess); with w = 1 the B^-1 of the spectral estimate
 template <int FMT>
@@ -311,7 +324,7 @@ template __global__ void k_restrict_blk<2>(int32_t, const int32_t*, const int32_
 // nodes), a half-wave one coarse node, a quad one member row of that node -- 64 fine rows per workgroup with the row loop of
 // k_spmv_lp / k_bsweep, i.e. the residual pass keeps its parallelism.  The member sums are formed in member order (as k_restrict
 // forms them: same bits); nodes of more than 8 members take further rounds.
-template <int FMT, int MODE>
+template <int FMT, int MODE, int GH>
 __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cslots, const int32_t* __restrict__ blk_rows_c,
                                                         const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
                                                         const uint8_t* __restrict__ free_mask, const int32_t* __restrict__ rowptr,
@@ -319,9 +332,12 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
                                                         const float* __restrict__ scale, const double* __restrict__ x,
                                                         const double* __restrict__ bvec, double* __restrict__ r_out,
                                                         double* __restrict__ bc, const float* __restrict__ dinv32_c,
-                                                        const void* __restrict__ binv_c, double omega_c, double* __restrict__ z_c) {
+                                                        const void* __restrict__ binv_c, double omega_c, double* __restrict__ z_c,
+                                                        GhostSrc gs) {
     __shared__ double sred[8][8][4];
     __shared__ double sbc[32];
+    GhostReader gr;
+    if (GH) gr.begin(gs);
     const int tid = threadIdx.x, hw = tid >> 5, q = (tid & 31) >> 2, c = tid & 3;
     const int32_t G = (int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x);          // the coarse smoother block of this workgroup
     const int32_t slot = G * 8 + hw;
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
             double sc = 1.0;
             if (FMT == 2) sc = (double)scale[4 * (int64_t)row + c];
             const double pre_b = bvec[4 * (int64_t)row + c];
-            const double res = pre_b - sc * lp_row_times_x<FMT>(rs, re, colind, vals_v, x, c);
+            const double res = pre_b - sc * lp_row_times_x<FMT, GH>(rs, re, colind, vals_v, x, c, &gr, &gs);
             r_out[4 * (int64_t)row + c] = res;
             v = (!free_mask || free_mask[4 * (int64_t)row + c]) ? res : 0.0;
         }
@@ -370,11 +386,13 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
         }
     }
 }
-#define SNS_INST_RR(F, M)                                                                                                        \
-    template __global__ void k_resid_restrict<F, M>(int32_t, int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, \
-                                                    const int32_t*, const int32_t*, const void*, const float*, const double*,    \
-                                                    const double*, double*, double*, const float*, const void*, double, double*);
-SNS_INST_RR(1, 0) SNS_INST_RR(1, 1) SNS_INST_RR(1, 2) SNS_INST_RR(2, 0) SNS_INST_RR(2, 1) SNS_INST_RR(2, 2)
+#define SNS_INST_RR(F, M, G)                                                                                                        \
+    template __global__ void k_resid_restrict<F, M, G>(int32_t, int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, \
+                                                       const int32_t*, const int32_t*, const void*, const float*, const double*,    \
+                                                       const double*, double*, double*, const float*, const void*, double, double*, \
+                                                       GhostSrc);
+SNS_INST_RR(1, 0, 0) SNS_INST_RR(1, 1, 0) SNS_INST_RR(1, 2, 0) SNS_INST_RR(2, 0, 0) SNS_INST_RR(2, 1, 0) SNS_INST_RR(2, 2, 0)
+SNS_INST_RR(1, 0, 1) SNS_INST_RR(1, 1, 1) SNS_INST_RR(1, 2, 1) SNS_INST_RR(2, 0, 1) SNS_INST_RR(2, 1, 1) SNS_INST_RR(2, 2, 1)
 #undef SNS_INST_RR
 
 // B_G^-1 of every smoother block from the level's fp64 operator: 8 blocks per workgroup, 32 lanes each (lane j = column j of the

@@ -32,22 +32,29 @@ namespace sns {
 
 
 // ---- peer transport: device side ------------------------------------------------------------------------------------------
-// Memory model: the windows are fine-grained device memory; a sender's payload stores are followed by a system-scope fence and
-// a system-scope release store of the sequence flag; a receiver polls the flag with system-scope acquire loads and reads the
-// payload with system-scope loads (never through a stale cache line of an earlier exchange).  Every wait is bounded by the
-// communicator's timeout and reports through the mapped error word instead of spinning for ever.
+// Memory model (sns_peer_dev.h): payload stores -> system-scope fence -> system-scope release store of the round number; the
+// receiver polls the round with system-scope acquire loads, every lane executes a system-scope acquire fence and reads the
+// payload with plain loads issued after it.  Every wait is bounded by the communicator's timeout and reports through the mapped
+// error word instead of spinning for ever.  Round numbers live in device memory and are advanced by the kernels.
 namespace {
 
-// halo put: the owned values listed in send_idx go straight into the neighbours' receive buffers; the last workgroup to
-// finish raises this rank's flag in every neighbour's window (also across links that carry no payload in this direction: the
-// flag is what keeps a rank from running two exchanges ahead of a neighbour, see comm_exchange)
-__global__ __launch_bounds__(256) void k_peer_put(int32_t ns, int nn, const int32_t* __restrict__ send_idx,
+__device__ __forceinline__ unsigned long long ld_round(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// halo put: the owned values listed in send_idx go straight into the neighbours' receive buffers of round *seq_dev + 1; the last
+// workgroup to finish raises this rank's flag in every neighbour's window (also across links that carry no payload in this
+// direction: the flag is what keeps a rank from running two exchanges ahead of a neighbour, see comm_exchange) and stores the
+// round.  rflag == nullptr (team transport): no flags, the host barrier orders the rounds.
+__global__ __launch_bounds__(256) void k_halo_put(int32_t ns, int nn, const int32_t* __restrict__ send_idx,
                                                   const int32_t* __restrict__ send_ptr, const double* __restrict__ x,
                                                   double* const* __restrict__ put, unsigned long long* const* __restrict__ rflag,
-                                                  unsigned long long seq, unsigned int* __restrict__ done) {
+                                                  unsigned long long* __restrict__ seq_dev, unsigned int* __restrict__ done) {
     __shared__ int32_t sp[PEER_MAX_RANKS + 1];
     __shared__ int last;
     const int tid = threadIdx.x;
+    const unsigned long long seq = ld_round(seq_dev) + 1ull;
+    double* const* __restrict__ dst = put + (size_t)(seq & 1ull) * nn;
     if (tid <= nn) sp[tid] = send_ptr[tid];
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * 256 + tid;        // one lane per half node: 16-byte loads and stores
@@ -57,28 +64,39 @@ __global__ __launch_bounds__(256) void k_peer_put(int32_t ns, int nn, const int3
         int k = 0;
         while (k + 1 < nn && i >= sp[k + 1]) ++k;
         const double2 v = *reinterpret_cast<const double2*>(x + 4 * (int64_t)send_idx[i] + 2 * hh);
-        *reinterpret_cast<double2*>(put[k] + 4 * (int64_t)(i - sp[k]) + 2 * hh) = v;
+        *reinterpret_cast<double2*>(dst[k] + 4 * (int64_t)(i - sp[k]) + 2 * hh) = v;
     }
-    __threadfence_system();
+    if (rflag) __threadfence_system();
     __syncthreads();
     if (tid == 0) last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (last) {
-        __threadfence_system();
-        if (tid < nn) peer_flag_store(rflag[tid], seq);
-        if (tid == 0) *done = 0u;
+        if (rflag) {
+            __threadfence_system();
+            if (tid < nn) peer_flag_store(rflag[tid], seq);
+        }
+        if (tid == 0) {
+            *done = 0u;
+            __hip_atomic_store(seq_dev, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
-// halo wait + unpack: every workgroup waits for all neighbours' flags, then scatters its part of the receive buffer
-__global__ __launch_bounds__(256) void k_peer_wait_unpack(int32_t nr, int nn, const int32_t* __restrict__ recv_idx,
-                                                          const double* __restrict__ recv_buf,
-                                                          const unsigned long long* __restrict__ flag, unsigned long long seq,
-                                                          double* __restrict__ x, int* err, long long timeout_ticks) {
+// halo wait + unpack (the exchanges outside the level passes: setup, estimates, Newton's state): every workgroup waits for all
+// neighbours' flags of the round the put in front of it left in *seq_dev, then scatters its part of the receive buffer
+__global__ __launch_bounds__(256) void k_peer_wait_unpack(int32_t nr, int nn_wait, const int32_t* __restrict__ recv_idx,
+                                                          const double* __restrict__ win0, const double* __restrict__ win1,
+                                                          const unsigned long long* __restrict__ flag,
+                                                          const unsigned long long* __restrict__ seq_dev, double* __restrict__ x,
+                                                          int* err, long long timeout_ticks) {
     const int tid = threadIdx.x;
-    if (tid < nn) (void)peer_flag_wait(flag + tid, seq, timeout_ticks, err, 1);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");             // every lane: nothing older than the flags is read below
+    const unsigned long long seq = ld_round(seq_dev);
+    const double* __restrict__ recv_buf = (seq & 1ull) ? win1 : win0;
+    if (nn_wait > 0) {
+        if (tid < nn_wait) (void)peer_flag_wait(flag + tid, seq, timeout_ticks, err, 1);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");         // every lane: nothing older than the flags is read below
+    }
     const int64_t t = (int64_t)blockIdx.x * 256 + tid;        // one lane per half node
     const int32_t i = (int32_t)(t >> 1);
     if (i < nr) {
@@ -93,15 +111,21 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(double* __restrict__ buf
     peer_allreduce_block(buf, count, a);
 }
 
-// all-gather, put half: workgroup (b, r) copies its share of this rank's m doubles into rank r's staging area; the last
-// workgroup of column r raises the flag there
-__global__ __launch_bounds__(256) void k_peer_ag_put(const double* __restrict__ send, int64_t m, unsigned long long seq, int rank,
-                                                     int64_t stage_doubles, double* const* __restrict__ ag,
-                                                     PeerCtl* const* __restrict__ ctl, unsigned int* __restrict__ done) {
+// all-gather, put half: workgroup (b, r) copies its share of this rank's doubles into rank r's staging area (slot `rank` of the
+// round's parity); the last workgroup of column r raises the flag there.  cnt == nullptr: m doubles from send + 0;
+// else cnt[rank] doubles (all-gather of ragged pieces).  Round = *seq_dev + 1 (advanced by the wait half).
+__global__ __launch_bounds__(256) void k_peer_ag_put(const double* __restrict__ send, int64_t m_uniform,
+                                                     const int64_t* __restrict__ cnt, int64_t slot_doubles,
+                                                     const unsigned long long* __restrict__ seq_dev, int rank, int64_t stage_doubles,
+                                                     double* const* __restrict__ ag, PeerCtl* const* __restrict__ ctl,
+                                                     unsigned int* __restrict__ done, int flags) {
     __shared__ int last;
     const int tid = threadIdx.x, r = blockIdx.y;
-    double* __restrict__ dst = ag[r] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)rank * m;
+    const unsigned long long seq = ld_round(seq_dev) + 1ull;
+    const int64_t m = cnt ? cnt[rank] : m_uniform;
+    double* __restrict__ dst = ag[r] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)rank * slot_doubles;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = send[i];
+    if (!flags) return;
     __threadfence_system();
     __syncthreads();
     if (tid == 0) last = (atomicAdd(done + r, 1u) == gridDim.x - 1) ? 1 : 0;
@@ -112,18 +136,34 @@ __global__ __launch_bounds__(256) void k_peer_ag_put(const double* __restrict__ 
         done[r] = 0u;
     }
 }
-// all-gather, wait half: workgroup (b, r) waits for rank r's flag and copies r's m doubles from the own staging area
-__global__ __launch_bounds__(256) void k_peer_ag_wait_copy(double* __restrict__ recv, int64_t count, int64_t off, int64_t m,
-                                                           unsigned long long seq, int rank, int64_t stage_doubles,
+// all-gather, wait half: workgroup (b, r) waits for rank r's flag and copies r's doubles from the own staging area to
+// recv + (off ? off[r] : r * count + chunk_off); the last workgroup of the grid stores the round
+__global__ __launch_bounds__(256) void k_peer_ag_wait_copy(double* __restrict__ recv, int64_t count, int64_t chunk_off,
+                                                           int64_t m_uniform, const int64_t* __restrict__ cnt,
+                                                           const int64_t* __restrict__ off, int64_t slot_doubles,
+                                                           unsigned long long* __restrict__ seq_dev, int rank, int64_t stage_doubles,
                                                            double* const* __restrict__ ag, PeerCtl* const* __restrict__ ctl,
-                                                           int* err, long long timeout_ticks) {
+                                                           unsigned int* __restrict__ done_all, int flags, int* err,
+                                                           long long timeout_ticks) {
+    __shared__ int last;
     const int tid = threadIdx.x, r = blockIdx.y;
-    if (tid == 0) (void)peer_flag_wait(&ctl[rank]->ag_flag[r], seq, timeout_ticks, err, 3);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    const double* __restrict__ src = ag[rank] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)r * m;
-    double* __restrict__ dst = recv + (int64_t)r * count + off;
+    const unsigned long long seq = ld_round(seq_dev) + 1ull;
+    if (flags) {
+        if (tid == 0) (void)peer_flag_wait(&ctl[rank]->ag_flag[r], seq, timeout_ticks, err, 3);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    const int64_t m = cnt ? cnt[r] : m_uniform;
+    const double* __restrict__ src = ag[rank] + (int64_t)(seq & 1ull) * stage_doubles + (int64_t)r * slot_doubles;
+    double* __restrict__ dst = recv + (off ? off[r] : (int64_t)r * count + chunk_off);
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    __syncthreads();
+    if (tid == 0) last = (atomicAdd(done_all, 1u) == gridDim.x * gridDim.y - 1) ? 1 : 0;
+    __syncthreads();
+    if (last && tid == 0) {
+        *done_all = 0u;
+        __hip_atomic_store(seq_dev, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace
@@ -145,6 +185,17 @@ void Team::barrier() {
         cv.wait(lk, [&] { return gen != g; });
     }
 }
+Team::~Team() {
+    for (Peer* p : peers)
+        if (p) (void)peer_destroy(p);
+}
+
+int comm_host_barrier(Comm* c, hipStream_t s) {
+    if (!c || !c->team) return SNS_OK;
+    CHIP(hipStreamSynchronize(s));
+    c->team->barrier();
+    return SNS_OK;
+}
 
 int plan_upload(Plan& p) {
     const size_t ns = (size_t)p.n_send(), nr = (size_t)p.n_recv();
@@ -154,6 +205,9 @@ int plan_upload(Plan& p) {
     if (nr) CHIP(hipMemcpy(p.recv_idx, p.h_recv_idx.data(), nr * sizeof(int32_t), hipMemcpyHostToDevice));
     CHIP(hipMalloc((void**)&p.send_buf, std::max<size_t>(1, 4 * ns) * sizeof(double)));
     CHIP(hipMalloc((void**)&p.recv_buf, std::max<size_t>(1, 4 * nr) * sizeof(double)));
+    p.identity_recv = true;
+    for (size_t q = 0; q < nr; ++q)
+        if (p.h_recv_idx[q] != p.n_own + (int32_t)q) { p.identity_recv = false; break; }
     return SNS_OK;
 }
 
@@ -163,16 +217,57 @@ void plan_free(Plan& p) {
     if (p.send_buf) (void)hipFree(p.send_buf);
     if (p.recv_buf) (void)hipFree(p.recv_buf);
     if (p.d_send_ptr) (void)hipFree(p.d_send_ptr);
-    if (p.d_recv_ptr) (void)hipFree(p.d_recv_ptr);
     if (p.d_put) (void)hipFree(p.d_put);
     if (p.d_rflag) (void)hipFree(p.d_rflag);
     if (p.d_done) (void)hipFree(p.d_done);
+    if (p.d_seq) (void)hipFree(p.d_seq);
     p.send_idx = p.recv_idx = nullptr;
     p.send_buf = p.recv_buf = nullptr;
-    p.d_send_ptr = p.d_recv_ptr = nullptr;
+    p.d_send_ptr = nullptr;
     p.d_put = nullptr;
     p.d_rflag = nullptr;
     p.d_done = nullptr;
+    p.d_seq = nullptr;
+    if (p.owner && p.win_recv[0]) {
+        // the plan area of a window is a bump allocator: it is reclaimed as a whole when the last plan carved from it goes
+        // (a communicator reused across problems -- bench legs, test suites -- would exhaust its window otherwise)
+        if (--p.owner->plans_live <= 0) {
+            p.owner->plans_live = 0;
+            p.owner->bump = p.owner->bump0;
+            p.owner->flag_bump = p.owner->flag_off;
+        }
+    }
+    p.owner = nullptr;
+    p.win_recv[0] = p.win_recv[1] = nullptr;
+    p.win_flag = nullptr;
+}
+
+// window transports: the put half of an exchange
+int comm_put(Comm* c, const Plan& p, const double* x, hipStream_t s) {
+    if (!c || !c->peer) { set_error("comm_put: no window transport"); return SNS_E_STATE; }
+    const int nn = (int)p.nbr.size();
+    if (nn == 0) return comm_host_barrier(c, s);             // (team: every rank passes the barrier of every exchange)
+    if (!p.d_put) { set_error("peer transport: halo plan was not connected"); return SNS_E_STATE; }
+    CTRY(peer_check(c));
+    const int32_t ns = p.n_send();
+    const unsigned gp = (unsigned)std::max<int64_t>(1, (2 * (int64_t)ns + 255) / 256);
+    hipLaunchKernelGGL(k_halo_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put,
+                       c->peer->host_sync ? (unsigned long long* const*)nullptr : p.d_rflag, p.d_seq, p.d_done);
+    return comm_host_barrier(c, s);
+}
+
+GhostSrc comm_ghost_src(const Comm* c, const Plan& p) {
+    GhostSrc g;
+    if (!c || !c->peer || p.nbr.empty() || !p.win_recv[0] || !p.identity_recv) return g;
+    g.win[0] = p.win_recv[0] - 4 * (int64_t)p.n_own;
+    g.win[1] = p.win_recv[1] - 4 * (int64_t)p.n_own;
+    g.n_own = p.n_own;
+    g.nn = c->peer->host_sync ? 0 : (int)p.nbr.size();
+    g.seq = p.d_seq;
+    g.flag = p.win_flag;
+    g.err = c->peer->err_dev;
+    g.timeout_ticks = c->peer->timeout_ticks;
+    return g;
 }
 
 int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
@@ -180,64 +275,32 @@ int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s) {
     const int nn = (int)p.nbr.size();
     const int32_t ns = p.n_send(), nr = p.n_recv();
     if (c->peer) {
-        // Flow control without acknowledgements: the receive buffers are double-buffered by the parity of the plan's sequence
-        // number, and this rank can start exchange s + 2 only after it has seen every neighbour's flag s + 1, which that
-        // neighbour raised after (stream order) it had unpacked exchange s -- the buffer about to be overwritten.
+        // Flow control without acknowledgements: the receive buffers are double-buffered by the parity of the plan's round, and
+        // this rank can start exchange s + 2 only after it has seen every neighbour's flag s + 1, which that neighbour raised
+        // after (stream order) it had consumed exchange s -- the buffer about to be overwritten.
         Peer* pe = c->peer;
+        CTRY(comm_put(c, p, x, s));
         if (nn == 0) return SNS_OK;
-        if (!p.d_put) { set_error("peer transport: halo plan was not connected"); return SNS_E_STATE; }
-        CTRY(peer_check(c));
-        const unsigned long long seq = ++p.seq;
-        const int par = (int)(seq & 1ull);
-        const unsigned gp = (unsigned)std::max<int64_t>(1, (2 * (int64_t)ns + 255) / 256);
-        hipLaunchKernelGGL(k_peer_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put + (size_t)par * nn,
-                           p.d_rflag, seq, p.d_done);
         const unsigned gu = (unsigned)std::max<int64_t>(1, (2 * (int64_t)nr + 255) / 256);
-        hipLaunchKernelGGL(k_peer_wait_unpack, dim3(gu), dim3(256), 0, s, nr, nn, p.recv_idx, p.win_recv[par], p.win_flag, seq, x,
-                           pe->err_dev, pe->timeout_ticks);
+        hipLaunchKernelGGL(k_peer_wait_unpack, dim3(gu), dim3(256), 0, s, nr, pe->host_sync ? 0 : nn, p.recv_idx, p.win_recv[0],
+                           p.win_recv[1], p.win_flag, p.d_seq, x, pe->err_dev, pe->timeout_ticks);
         return SNS_OK;
     }
+    if (!c->nccl) { set_error("comm_exchange: no transport"); return SNS_E_STATE; }
     if (ns > 0)
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((4 * (int64_t)ns + 255) / 256)), dim3(256), 0, s, ns, p.send_idx, x,
                            p.send_buf);
-    if (c->nccl) {
-        if (nn > 0) {
-            CNCCL(ncclGroupStart());
-            for (int k = 0; k < nn; ++k) {
-                const int32_t s0 = p.send_ptr[k], s1 = p.send_ptr[k + 1];
-                const int32_t r0 = p.recv_ptr[k], r1 = p.recv_ptr[k + 1];
-                if (s1 > s0)
-                    CNCCL(ncclSend(p.send_buf + 4 * (int64_t)s0, 4 * (size_t)(s1 - s0), ncclDouble, p.nbr[k], c->nccl, s));
-                if (r1 > r0)
-                    CNCCL(ncclRecv(p.recv_buf + 4 * (int64_t)r0, 4 * (size_t)(r1 - r0), ncclDouble, p.nbr[k], c->nccl, s));
-            }
-            CNCCL(ncclGroupEnd());
-        }
-    } else {
-        Team* t = c->team;
-        CHIP(hipStreamSynchronize(s));                       // my packed data is complete
-        t->pub_buf[c->rank] = p.send_buf;
-        t->pub_plan[c->rank] = &p;
-        t->barrier();
+    if (nn > 0) {
+        CNCCL(ncclGroupStart());
         for (int k = 0; k < nn; ++k) {
-            const int peer = p.nbr[k];
+            const int32_t s0 = p.send_ptr[k], s1 = p.send_ptr[k + 1];
             const int32_t r0 = p.recv_ptr[k], r1 = p.recv_ptr[k + 1];
-            if (r1 <= r0) continue;
-            const Plan* pp = t->pub_plan[peer];
-            int kk = -1;
-            for (size_t q = 0; q < pp->nbr.size(); ++q)
-                if (pp->nbr[q] == c->rank) kk = (int)q;
-            if (kk < 0 || pp->send_ptr[kk + 1] - pp->send_ptr[kk] != r1 - r0) {
-                set_error("team exchange: plans of rank " + std::to_string(c->rank) + " and " + std::to_string(peer) +
-                          " disagree");
-                t->barrier();
-                return SNS_E_COMM;
-            }
-            CHIP(hipMemcpyAsync(p.recv_buf + 4 * (int64_t)r0, t->pub_buf[peer] + 4 * (int64_t)pp->send_ptr[kk],
-                                4 * (size_t)(r1 - r0) * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (s1 > s0)
+                CNCCL(ncclSend(p.send_buf + 4 * (int64_t)s0, 4 * (size_t)(s1 - s0), ncclDouble, p.nbr[k], c->nccl, s));
+            if (r1 > r0)
+                CNCCL(ncclRecv(p.recv_buf + 4 * (int64_t)r0, 4 * (size_t)(r1 - r0), ncclDouble, p.nbr[k], c->nccl, s));
         }
-        CHIP(hipStreamSynchronize(s));
-        t->barrier();                                        // peers may now reuse their send buffers
+        CNCCL(ncclGroupEnd());
     }
     if (nr > 0)
         hipLaunchKernelGGL(k_unpack, dim3((unsigned)((4 * (int64_t)nr + 255) / 256)), dim3(256), 0, s, nr, p.recv_idx,
@@ -252,7 +315,13 @@ int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t s) {
         CTRY(peer_check(c));
         for (int off = 0; off < count; off += PEER_AR_MAX) {
             const int m = std::min(PEER_AR_MAX, count - off);
-            hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, peer_next_allreduce(pe));
+            if (pe->host_sync) {
+                hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, peer_allreduce_args(pe, 1));
+                CTRY(comm_host_barrier(c, s));
+                hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, peer_allreduce_args(pe, 2));
+            } else {
+                hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(256), 0, s, buf + off, m, peer_allreduce_args(pe, 0));
+            }
         }
         return SNS_OK;
     }
@@ -260,20 +329,26 @@ int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t s) {
         CNCCL(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->nccl, s));
         return SNS_OK;
     }
-    Team* t = c->team;
-    std::vector<double>& mine = t->slots[c->rank];
-    mine.resize(count);
-    CHIP(hipMemcpyAsync(mine.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, s));
-    CHIP(hipStreamSynchronize(s));
-    t->barrier();
-    std::vector<double> sum(count, 0.0);
-    for (int r = 0; r < t->n; ++r)                           // fixed order => identical bits on every rank
-        for (int i = 0; i < count; ++i) sum[i] += t->slots[r][i];
-    t->barrier();
-    CHIP(hipMemcpyAsync(buf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice, s));
-    CHIP(hipStreamSynchronize(s));                           // `sum` is a stack buffer
+    set_error("comm_allreduce_sum: no transport");
+    return SNS_E_STATE;
+}
+
+namespace {
+// one chunk of an all-gather over the windows: m doubles per rank (uniform) or cnt[r] (ragged, <= slot doubles each)
+int peer_allgather_chunk(Comm* c, const double* send, double* recv, int64_t count, int64_t chunk_off, int64_t m,
+                         const int64_t* cnt, const int64_t* off, int64_t slot, hipStream_t s) {
+    Peer* pe = c->peer;
+    const int flags = pe->host_sync ? 0 : 1;
+    const unsigned gb = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
+    hipLaunchKernelGGL(k_peer_ag_put, dim3(gb, pe->nranks), dim3(256), 0, s, send, m, cnt, slot, pe->d_seq + 1, pe->rank,
+                       (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->d_done, flags);
+    CTRY(comm_host_barrier(c, s));
+    hipLaunchKernelGGL(k_peer_ag_wait_copy, dim3(gb, pe->nranks), dim3(256), 0, s, recv, count, chunk_off, m, cnt, off, slot,
+                       pe->d_seq + 1, pe->rank, (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->d_done + PEER_MAX_RANKS, flags,
+                       pe->err_dev, pe->timeout_ticks);
     return SNS_OK;
 }
+}  // namespace
 
 int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStream_t s) {
     if (!c || !c->active() || c->nranks <= 1) {
@@ -286,12 +361,7 @@ int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStre
         const int64_t per = (int64_t)(pe->ag_doubles / (size_t)pe->nranks);          // doubles per rank and chunk
         for (int64_t off = 0; off < count; off += per) {
             const int64_t m = std::min<int64_t>(per, count - off);
-            const unsigned long long seq = ++pe->ag_seq;
-            const unsigned gb = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
-            hipLaunchKernelGGL(k_peer_ag_put, dim3(gb, pe->nranks), dim3(256), 0, s, send + off, m, seq, pe->rank,
-                               (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->d_done);
-            hipLaunchKernelGGL(k_peer_ag_wait_copy, dim3(gb, pe->nranks), dim3(256), 0, s, recv, (int64_t)count, off, m, seq,
-                               pe->rank, (int64_t)pe->ag_doubles, pe->d_ag, pe->d_ctl, pe->err_dev, pe->timeout_ticks);
+            CTRY(peer_allgather_chunk(c, send + off, recv, (int64_t)count, off, m, nullptr, nullptr, m, s));
         }
         return SNS_OK;
     }
@@ -299,18 +369,18 @@ int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStre
         CNCCL(ncclAllGather(send, recv, count, ncclDouble, c->nccl, s));
         return SNS_OK;
     }
-    Team* t = c->team;
-    std::vector<double>& mine = t->slots[c->rank];
-    mine.resize(count);
-    CHIP(hipMemcpyAsync(mine.data(), send, count * sizeof(double), hipMemcpyDeviceToHost, s));
-    CHIP(hipStreamSynchronize(s));
-    t->barrier();
-    std::vector<double> all((size_t)count * t->n);
-    for (int r = 0; r < t->n; ++r) std::memcpy(all.data() + (size_t)r * count, t->slots[r].data(), count * sizeof(double));
-    t->barrier();
-    CHIP(hipMemcpyAsync(recv, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    CHIP(hipStreamSynchronize(s));
-    return SNS_OK;
+    set_error("comm_allgather: no transport");
+    return SNS_E_STATE;
+}
+
+int comm_allgatherv(Comm* c, const double* send, double* recv, int max_count, const int64_t* dev_off, const int64_t* dev_cnt,
+                    hipStream_t s) {
+    if (!c || !c->peer) { set_error("comm_allgatherv: window transports only"); return SNS_E_STATE; }
+    Peer* pe = c->peer;
+    CTRY(peer_check(c));
+    const int64_t per = (int64_t)(pe->ag_doubles / (size_t)pe->nranks);
+    if (max_count > per) { set_error("comm_allgatherv: piece larger than the staging area"); return SNS_E_ARG; }
+    return peer_allgather_chunk(c, send, recv, 0, 0, (int64_t)max_count, dev_cnt, dev_off, (int64_t)max_count, s);
 }
 
 // ---- peer transport: host side ----------------------------------------------------------------------------------------------
@@ -321,7 +391,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int peer_create(int device, int rank, int nranks, size_t window_bytes, Peer** out, char handle_out[64]) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
-    if (!out || !handle_out || nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) {
+    if (!out || nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) {
         set_error("sns_peer_create: bad arguments (at most " + std::to_string(PEER_MAX_RANKS) + " ranks)");
         return SNS_E_ARG;
     }
@@ -343,22 +413,29 @@ int peer_create(int device, int rank, int nranks, size_t window_bytes, Peer** ou
     p->base[rank] = static_cast<char*>(w);
     CHIP(hipMemset(w, 0, window_bytes));
     CHIP(hipDeviceSynchronize());
-    // control area | all-gather staging (2 parities, a quarter of the window each at most 32 MiB) | plan area
-    p->ag_off = PEER_CTL_BYTES;
+    // control area | the plans' arrival flags (64 KiB, flags only) | all-gather staging (2 parities, a quarter of the window each
+    // at most 32 MiB) | plan area (receive buffers)
+    p->flag_off = p->flag_bump = PEER_CTL_BYTES;
+    p->flag_end = p->flag_off + ((size_t)64 << 10);
+    p->ag_off = p->flag_end;
     const size_t ag_bytes = std::min<size_t>((size_t)32 << 20, window_bytes / 4) / (8 * (size_t)nranks) * (8 * (size_t)nranks);
     p->ag_doubles = ag_bytes / 8;
-    p->bump = align_up(p->ag_off + 2 * ag_bytes, 4096);
+    p->bump = p->bump0 = align_up(p->ag_off + 2 * ag_bytes, 4096);
     CHIP(hipHostMalloc((void**)&p->err_host, sizeof(int), hipHostMallocMapped));
     *p->err_host = 0;
     CHIP(hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0));
-    CHIP(hipMalloc((void**)&p->d_done, PEER_MAX_RANKS * sizeof(unsigned int)));
-    CHIP(hipMemset(p->d_done, 0, PEER_MAX_RANKS * sizeof(unsigned int)));
+    CHIP(hipMalloc((void**)&p->d_done, (PEER_MAX_RANKS + 1) * sizeof(unsigned int)));
+    CHIP(hipMemset(p->d_done, 0, (PEER_MAX_RANKS + 1) * sizeof(unsigned int)));
+    CHIP(hipMalloc((void**)&p->d_seq, 2 * sizeof(unsigned long long)));
+    CHIP(hipMemset(p->d_seq, 0, 2 * sizeof(unsigned long long)));
     double ms = 20000.0;
     if (const char* t = std::getenv("SNS_PEER_TIMEOUT_MS")) ms = std::max(1.0, std::atof(t));
     p->timeout_ticks = (long long)(ms * 1.0e5);                                  // wall_clock64(): 100 MHz
-    hipIpcMemHandle_t hd;
-    CHIP(hipIpcGetMemHandle(&hd, w));
-    std::memcpy(handle_out, &hd, 64);
+    if (handle_out) {
+        hipIpcMemHandle_t hd;
+        CHIP(hipIpcGetMemHandle(&hd, w));
+        std::memcpy(handle_out, &hd, 64);
+    }
     *out = p.release();
     return SNS_OK;
 }
@@ -395,29 +472,43 @@ int peer_finish_connect(Peer* p) {
     return SNS_OK;
 }
 
-int peer_destroy(Peer* p) {
+// Teardown in two phases (the IPC contract leaves freeing a window that a peer still has mapped undefined): every rank closes
+// its mappings of the others' windows, the ranks synchronise (caller), then every rank frees its own window.
+int peer_close_mappings(Peer* p) {
     if (!p) return SNS_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     for (int r = 0; r < p->nranks; ++r)
-        if (p->mapped[r] && p->base[r]) (void)hipIpcCloseMemHandle(p->base[r]);
+        if (p->mapped[r] && p->base[r]) {
+            (void)hipIpcCloseMemHandle(p->base[r]);
+            p->mapped[r] = false;
+            p->base[r] = nullptr;
+        }
+    return SNS_OK;
+}
+
+int peer_destroy(Peer* p) {
+    if (!p) return SNS_OK;
+    (void)peer_close_mappings(p);                            // (no-op after an explicit first phase)
     if (p->base[p->rank]) (void)hipFree(p->base[p->rank]);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_ag) (void)hipFree(p->d_ag);
     if (p->d_done) (void)hipFree(p->d_done);
+    if (p->d_seq) (void)hipFree(p->d_seq);
     if (p->err_host) (void)hipHostFree(p->err_host);
     delete p;
     return SNS_OK;
 }
 
-PeerArgs peer_next_allreduce(Peer* p) {
+PeerArgs peer_allreduce_args(Peer* p, int phase) {
     PeerArgs a;
-    a.seq = ++p->ar_seq;
+    a.seq = p->d_seq;
     a.rank = p->rank;
     a.nranks = p->nranks;
     a.ctl = p->d_ctl;
     a.err = p->err_dev;
     a.timeout_ticks = p->timeout_ticks;
+    a.phase = phase;
     return a;
 }
 
@@ -437,20 +528,26 @@ int peer_plan_offer(Comm* c, Plan& p, PlanOffers& t) {
     Peer* pe = c->peer;
     const int nr_ranks = pe->nranks, nn = (int)p.nbr.size();
     if (!pe->connected) { set_error("peer transport: sns_peer_connect has not been called"); return SNS_E_STATE; }
-    t.mine.assign((size_t)3 * nr_ranks, -1.0);
-    const size_t flag_off = align_up(pe->bump, 256);
+    t.mine.assign((size_t)3 * nr_ranks + 1, -1.0);
+    const size_t flag_off = align_up(pe->flag_bump, 64);
     const size_t rbytes = align_up(std::max<size_t>(32, (size_t)p.n_recv() * 32), 256);
-    const size_t r0 = align_up(flag_off + (size_t)std::max(1, nn) * 8, 256), r1 = r0 + rbytes, end = r1 + rbytes;
-    if (end > pe->bytes) {
+    const size_t r0 = align_up(pe->bump, 256), r1 = r0 + rbytes, end = r1 + rbytes;
+    if (end > pe->bytes || flag_off + (size_t)std::max(1, nn) * 8 > pe->flag_end) {
         set_error("peer transport: window of " + std::to_string(pe->bytes >> 20) + " MiB exhausted (sns_peer_create window_bytes)");
         return SNS_E_COMM;
     }
     pe->bump = end;
+    pe->flag_bump = flag_off + (size_t)std::max(1, nn) * 8;
+    ++pe->plans_live;
+    p.owner = pe;
     char* own = pe->base[pe->rank];
     p.win_flag = reinterpret_cast<unsigned long long*>(own + flag_off);
     p.win_recv[0] = reinterpret_cast<double*>(own + r0);
     p.win_recv[1] = reinterpret_cast<double*>(own + r1);
-    p.seq = 0;
+    // (both areas are reused after a reclaim.  Nothing is cleared: the flag area only ever holds round numbers, and the rounds of a
+    // new plan start above every round any rank has used so far, see peer_plan_connect; stale payload is never read before the
+    // flags of its round have arrived)
+    t.mine[(size_t)3 * nr_ranks] = (double)pe->epoch;
     for (int k = 0; k < nn; ++k) {
         const int j = p.nbr[(size_t)k];
         if (j < 0 || j >= nr_ranks || j == pe->rank) continue;                    // (check_plan_symmetry reports it)
@@ -464,13 +561,19 @@ int peer_plan_offer(Comm* c, Plan& p, PlanOffers& t) {
 int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t) {
     Peer* pe = c->peer;
     const int nr_ranks = pe->nranks, nn = (int)p.nbr.size();
-    if (t.all.size() != (size_t)3 * nr_ranks * nr_ranks) { set_error("peer transport: bad offer table"); return SNS_E_COMM; }
+    const size_t LEN = (size_t)3 * nr_ranks + 1;
+    if (t.all.size() != LEN * nr_ranks) { set_error("peer transport: bad offer table"); return SNS_E_COMM; }
     if (nn > PEER_MAX_RANKS) { set_error("peer transport: too many neighbours"); return SNS_E_ARG; }
+    // first round of this plan: above every round of every earlier plan of any rank (the same number on every rank: the table is)
+    double ep = 0.0;
+    for (int r = 0; r < nr_ranks; ++r) ep = std::max(ep, t.all[(size_t)r * LEN + (size_t)3 * nr_ranks]);
+    pe->epoch = (long long)ep + 1;
+    const unsigned long long round0 = (unsigned long long)pe->epoch << 32;
     std::vector<double*> put((size_t)2 * std::max(1, nn), nullptr);
     std::vector<unsigned long long*> rflag((size_t)std::max(1, nn), nullptr);
     for (int k = 0; k < nn; ++k) {
         const int j = p.nbr[(size_t)k];
-        const double* o = t.all.data() + ((size_t)j * nr_ranks + pe->rank) * 3;   // what rank j offers to this rank
+        const double* o = t.all.data() + (size_t)j * LEN + (size_t)3 * pe->rank;      // what rank j offers to this rank
         if (o[0] < 0.0 || o[1] < 0.0 || o[2] < 0.0) {
             set_error("peer transport: rank " + std::to_string(j) + " does not list rank " + std::to_string(pe->rank) + " as a neighbour");
             return SNS_E_COMM;
@@ -479,19 +582,51 @@ int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t) {
         put[(size_t)nn + k] = reinterpret_cast<double*>(pe->base[j] + (size_t)o[1]);
         rflag[(size_t)k] = reinterpret_cast<unsigned long long*>(pe->base[j] + (size_t)o[2]);
     }
-    std::vector<int32_t> sp(p.send_ptr), rp(p.recv_ptr);
+    std::vector<int32_t> sp(p.send_ptr);
     if (sp.empty()) sp.assign(1, 0);
-    if (rp.empty()) rp.assign(1, 0);
     CHIP(hipMalloc((void**)&p.d_send_ptr, sp.size() * sizeof(int32_t)));
-    CHIP(hipMalloc((void**)&p.d_recv_ptr, rp.size() * sizeof(int32_t)));
     CHIP(hipMemcpy(p.d_send_ptr, sp.data(), sp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    CHIP(hipMemcpy(p.d_recv_ptr, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     CHIP(hipMalloc((void**)&p.d_put, put.size() * sizeof(double*)));
     CHIP(hipMalloc((void**)&p.d_rflag, rflag.size() * sizeof(unsigned long long*)));
     CHIP(hipMemcpy(p.d_put, put.data(), put.size() * sizeof(double*), hipMemcpyHostToDevice));
     CHIP(hipMemcpy(p.d_rflag, rflag.data(), rflag.size() * sizeof(unsigned long long*), hipMemcpyHostToDevice));
     CHIP(hipMalloc((void**)&p.d_done, sizeof(unsigned int)));
     CHIP(hipMemset(p.d_done, 0, sizeof(unsigned int)));
+    CHIP(hipMalloc((void**)&p.d_seq, sizeof(unsigned long long)));
+    CHIP(hipMemcpy(p.d_seq, &round0, sizeof(unsigned long long), hipMemcpyHostToDevice));
+    return SNS_OK;
+}
+
+// team transport: this rank's peer end on a window of its own, wired to the other ranks' windows inside the one address space
+// (what sns_peer_connect does through HIP IPC between processes).  Collective over the team's threads; a communicator is made
+// once per team and rank and shared by every handle attached to the team afterwards.
+int team_peer(Team* t, int device, int rank, Peer** out) {
+    if (!t || rank < 0 || rank >= t->n || !out) return SNS_E_ARG;
+    if (t->n > PEER_MAX_RANKS) { set_error("team transport: at most " + std::to_string(PEER_MAX_RANKS) + " ranks"); return SNS_E_ARG; }
+    if (!t->peers[(size_t)rank]) {
+        Peer* p = nullptr;
+        size_t wb = (size_t)64 << 20;
+        if (const char* e = std::getenv("SNS_TEAM_WINDOW_MB")) wb = (size_t)std::max(4, std::atoi(e)) << 20;
+        t->rc[(size_t)rank] = peer_create(device, rank, t->n, wb, &p, nullptr);
+        t->peers[(size_t)rank] = p;
+        const std::string err = sns_last_error();
+        t->barrier();                                        // every window exists (or its rank has recorded why not)
+        int rc = SNS_OK;
+        for (int q = 0; q < t->n; ++q)
+            if (t->rc[(size_t)q] != SNS_OK) rc = t->rc[(size_t)q];
+        if (rc == SNS_OK) {
+            for (int q = 0; q < t->n; ++q) p->base[q] = t->peers[(size_t)q]->base[q];
+            p->host_sync = true;
+            rc = peer_finish_connect(p);
+        } else if (t->rc[(size_t)rank] != SNS_OK) {
+            set_error(err);
+        } else {
+            set_error("team transport: another rank could not allocate its window");
+        }
+        t->barrier();
+        if (rc != SNS_OK) return rc;
+    }
+    *out = t->peers[(size_t)rank];
     return SNS_OK;
 }
 
@@ -508,6 +643,38 @@ __global__ void k_selftest_fill(int32_t n_nodes, double base, double* __restrict
 __global__ void k_selftest_check(int32_t n_nodes, double base, const double* __restrict__ x, int* __restrict__ bad) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < 4 * (int64_t)n_nodes && x[t] != base + (double)t) atomicAdd(bad, 1);
+}
+// the product's read path: ghost block k of the vector straight from the receive window (GhostReader, as the level passes do);
+// x is the vector itself (its tail is NOT read: poisoned by the caller)
+__global__ __launch_bounds__(256) void k_selftest_check_ghost(GhostSrc g, int32_t first_node, int32_t n_nodes, double base,
+                                                              const double* __restrict__ x, int* __restrict__ bad) {
+    GhostReader gr;
+    gr.begin(g);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = t < 4 * (int64_t)n_nodes;
+    const int32_t node = first_node + (int32_t)(in ? t >> 2 : 0);
+    gr.arrive(g, in && node >= gr.n_own);
+    if (in && gr.ptr(x, node)[t & 3] != base + (double)t) atomicAdd(bad, 1);
+}
+
+// a ring of halo links: rank r <-> r + 1 and r - 1 (one link with two ranks); the same owned nodes [0, halo) go to every
+// neighbour, ghost block k = nodes [halo * (1 + k), halo * (2 + k))
+void ring_plan(Plan& plan, int r, int nranks, int halo_nodes) {
+    const int nn = nranks == 2 ? 1 : 2;
+    plan.nbr.assign(1, (r + 1) % nranks);
+    if (nn == 2) plan.nbr.push_back((r + nranks - 1) % nranks);
+    std::sort(plan.nbr.begin(), plan.nbr.end());
+    plan.send_ptr.assign(1, 0);
+    plan.recv_ptr.assign(1, 0);
+    plan.n_own = halo_nodes;
+    for (int k = 0; k < nn; ++k) {
+        for (int i = 0; i < halo_nodes; ++i) {
+            plan.h_send_idx.push_back(i);
+            plan.h_recv_idx.push_back(halo_nodes * (1 + k) + i);
+        }
+        plan.send_ptr.push_back((int32_t)plan.h_send_idx.size());
+        plan.recv_ptr.push_back((int32_t)plan.h_recv_idx.size());
+    }
 }
 }  // namespace
 
@@ -548,20 +715,8 @@ int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_ou
         c.peer = pe;
         c.rank = r;
         c.nranks = nranks;
-        const int nn = nranks == 2 ? 1 : 2;
-        plan.nbr.assign(1, (r + 1) % nranks);
-        if (nn == 2) plan.nbr.push_back((r + nranks - 1) % nranks);
-        std::sort(plan.nbr.begin(), plan.nbr.end());
-        plan.send_ptr.assign(1, 0);
-        plan.recv_ptr.assign(1, 0);
-        for (int k = 0; k < nn; ++k) {
-            for (int i = 0; i < halo_nodes; ++i) {
-                plan.h_send_idx.push_back(i);                                    // the same owned nodes go to every neighbour
-                plan.h_recv_idx.push_back(halo_nodes * (1 + k) + i);             // ghost block k
-            }
-            plan.send_ptr.push_back((int32_t)plan.h_send_idx.size());
-            plan.recv_ptr.push_back((int32_t)plan.h_recv_idx.size());
-        }
+        ring_plan(plan, r, nranks, halo_nodes);
+        const int nn = (int)plan.nbr.size();
         const int32_t n_local = halo_nodes * (1 + nn);
         if (rcs[(size_t)r] == SNS_OK && plan_upload(plan) != SNS_OK) fail(SNS_E_HIP);
         if (rcs[(size_t)r] == SNS_OK && peer_plan_offer(&c, plan, offers[(size_t)r]) != SNS_OK) fail(SNS_E_COMM);
@@ -593,12 +748,22 @@ int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_ou
                     const double tag = 1.0e6 * (it + 1);
                     int rc2 = SNS_OK;
                     if (phase == 0) {
-                        // owned values = f(rank, round); after the exchange ghost block k must hold f(neighbour k, round)
+                        // owned values = f(rank, round); after the exchange ghost block k must hold f(neighbour k, round): odd rounds
+                        // through put + wait / unpack into the vector's tail, even rounds through put + the level passes' read
+                        // path (straight from the window, the wait inside the consumer)
                         hipLaunchKernelGGL(k_selftest_fill, dim3(gh), dim3(256), 0, st, halo_nodes, tag + 1.0e3 * r, x);
-                        rc2 = comm_exchange(&c, plan, x, st);
-                        for (int k = 0; k < nn; ++k)
-                            hipLaunchKernelGGL(k_selftest_check, dim3(gh), dim3(256), 0, st, halo_nodes, tag + 1.0e3 * plan.nbr[(size_t)k],
-                                               x + 4 * (size_t)halo_nodes * (1 + k), bad);
+                        if (it & 1) {
+                            rc2 = comm_exchange(&c, plan, x, st);
+                            for (int k = 0; k < nn; ++k)
+                                hipLaunchKernelGGL(k_selftest_check, dim3(gh), dim3(256), 0, st, halo_nodes, tag + 1.0e3 * plan.nbr[(size_t)k],
+                                                   x + 4 * (size_t)halo_nodes * (1 + k), bad);
+                        } else {
+                            rc2 = comm_put(&c, plan, x, st);
+                            const GhostSrc g = comm_ghost_src(&c, plan);
+                            for (int k = 0; k < nn; ++k)
+                                hipLaunchKernelGGL(k_selftest_check_ghost, dim3(gh), dim3(256), 0, st, g, halo_nodes * (1 + k), halo_nodes,
+                                                   tag + 1.0e3 * plan.nbr[(size_t)k], x, bad);
+                        }
                     } else if (phase == 1) {
                         hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(256), 0, st, 1, tag + (double)r, ar);      // 4 values
                         rc2 = comm_allreduce_sum(&c, ar, 4, st);
@@ -717,9 +882,11 @@ int peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_ou
 }
 
 // Link check of a CONNECTED communicator between its real ranks (collective; sns_peer_check_links): `rounds` all-reduces whose
-// contributions depend on rank and round and `rounds` all-gathers of 4096 patterned doubles per rank, every value verified.  What it
-// is for: the first contact of the windows with real xGMI links -- a visibility problem (a stale flag or payload read) shows up here
-// as SNS_E_COMM with a count, not later as a solve that quietly diverges.
+// contributions depend on rank and round, `rounds` all-gathers of 4096 patterned doubles per rank and -- ADVICE r4 -- `rounds` halo
+// exchanges over a ring plan between the real ranks (2048 nodes per direction, patterned payload), read alternately through the
+// wait / unpack kernel and through the level passes' own path (GhostSrc: wait inside the consumer, ghost entries straight from the
+// window), every value verified.  What it is for: the first contact of the windows with real xGMI links -- a visibility problem (a
+// stale flag or payload read) shows up here as SNS_E_COMM with a count, not later as a solve that quietly diverges.
 int peer_check_links(Peer* pe, int rounds) {
     if (!pe || !pe->connected || rounds < 1) { set_error("sns_peer_check_links: connected communicator, rounds >= 1"); return SNS_E_ARG; }
     CHIP(hipSetDevice(pe->device));
@@ -727,11 +894,12 @@ int peer_check_links(Peer* pe, int rounds) {
     c.peer = pe;
     c.rank = pe->rank;
     c.nranks = pe->nranks;
-    const int n = 4096, nr = pe->nranks;
+    const int n = 4096, nr = pe->nranks, halo = 2048;
     hipStream_t st = nullptr;
-    double *ar = nullptr, *ags = nullptr, *agr = nullptr;
+    double *ar = nullptr, *ags = nullptr, *agr = nullptr, *x = nullptr, *off_s = nullptr, *off_r = nullptr;
     int* bad = nullptr;
     int rc = SNS_OK, wrong = 0;
+    Plan plan;
     auto body = [&]() -> int {
         CHIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         CHIP(hipMalloc((void**)&ar, 8 * sizeof(double)));
@@ -759,6 +927,50 @@ int peer_check_links(Peer* pe, int rounds) {
         }
         CHIP(hipStreamSynchronize(st));
         CTRY(peer_check(&c));
+        if (nr >= 2) {
+            // the halo ring; its offers travel through the all-gather that has just been verified
+            ring_plan(plan, pe->rank, nr, halo);
+            const int nn = (int)plan.nbr.size();
+            CTRY(plan_upload(plan));
+            PlanOffers t;
+            const int rco = peer_plan_offer(&c, plan, t);
+            const size_t LEN = (size_t)3 * nr + 1;
+            if (rco != SNS_OK) t.mine.assign(LEN, -2.0);
+            CHIP(hipMalloc((void**)&off_s, LEN * sizeof(double)));
+            CHIP(hipMalloc((void**)&off_r, LEN * nr * sizeof(double)));
+            CHIP(hipMemcpy(off_s, t.mine.data(), LEN * sizeof(double), hipMemcpyHostToDevice));
+            CTRY(comm_allgather(&c, off_s, off_r, (int)LEN, st));
+            CHIP(hipStreamSynchronize(st));
+            CTRY(peer_check(&c));
+            t.all.resize(LEN * nr);
+            CHIP(hipMemcpy(t.all.data(), off_r, t.all.size() * sizeof(double), hipMemcpyDeviceToHost));
+            if (rco != SNS_OK) return rco;
+            for (double v : t.all)
+                if (v == -2.0) { set_error("peer link check: a rank could not place the ring plan in its window"); return SNS_E_COMM; }
+            CTRY(peer_plan_connect(&c, plan, t));
+            const int32_t n_local = halo * (1 + nn);
+            CHIP(hipMalloc((void**)&x, 4 * (size_t)n_local * sizeof(double)));
+            const unsigned gh = (unsigned)((4 * (int64_t)halo + 255) / 256);
+            for (int it = 0; it < rounds; ++it) {
+                const double tag = 5.0e6 * (it + 1);
+                CHIP(hipMemsetAsync(x, 0xff, 4 * (size_t)n_local * sizeof(double), st));              // poison (NaN pattern)
+                hipLaunchKernelGGL(k_selftest_fill, dim3(gh), dim3(256), 0, st, halo, tag + 1.0e3 * pe->rank, x);
+                if (it & 1) {
+                    CTRY(comm_exchange(&c, plan, x, st));
+                    for (int k = 0; k < nn; ++k)
+                        hipLaunchKernelGGL(k_selftest_check, dim3(gh), dim3(256), 0, st, halo, tag + 1.0e3 * plan.nbr[(size_t)k],
+                                           x + 4 * (size_t)halo * (1 + k), bad);
+                } else {
+                    CTRY(comm_put(&c, plan, x, st));
+                    const GhostSrc g = comm_ghost_src(&c, plan);
+                    for (int k = 0; k < nn; ++k)
+                        hipLaunchKernelGGL(k_selftest_check_ghost, dim3(gh), dim3(256), 0, st, g, halo * (1 + k), halo,
+                                           tag + 1.0e3 * plan.nbr[(size_t)k], x, bad);
+                }
+            }
+            CHIP(hipStreamSynchronize(st));
+            CTRY(peer_check(&c));
+        }
         int dbad = 0;
         CHIP(hipMemcpy(&dbad, bad, sizeof(int), hipMemcpyDeviceToHost));
         wrong += dbad;
@@ -766,7 +978,10 @@ int peer_check_links(Peer* pe, int rounds) {
     };
     rc = body();
     if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    (void)hipFree(ar); (void)hipFree(ags); (void)hipFree(agr); (void)hipFree(bad);
+    // (the ring plan's area goes back to the window; a peer still a round behind only ever writes rounds of THIS plan, which no
+    // later plan mistakes for its own -- peer_plan_connect)
+    plan_free(plan);
+    (void)hipFree(ar); (void)hipFree(ags); (void)hipFree(agr); (void)hipFree(bad); (void)hipFree(x); (void)hipFree(off_s); (void)hipFree(off_r);
     if (rc == SNS_OK && wrong != 0) {
         set_error("peer link check: rank " + std::to_string(pe->rank) + " read " + std::to_string(wrong) + " wrong values in " +
                   std::to_string(rounds) + " rounds (stores of a peer not visible: window memory type / peer access)");

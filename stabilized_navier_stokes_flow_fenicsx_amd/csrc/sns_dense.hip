@@ -16,7 +16,8 @@
 // terms on the velocity block, the PSPG Laplacian on the pressure block; Dirichlet and empty coarse dofs are identity rows), so
 // every leading principal block is nonsingular and the element growth of the elimination is bounded by the ratio of the skew
 // to the symmetric part -- 1e2..1e4 on the convection-dominated coarse levels, harmless in fp64.  A pivot that is zero or not
-// finite raises *singular, and the host falls back to the smoothed hierarchy.
+// finite raises *singular, and the numeric setup returns SNS_E_STATE on EVERY rank (pc_setup sums the flag over the ranks; there is no
+// fallback hierarchy: the message names the options -- amg_dense_rows = 0 / amg_block_smooth = 0 -- that take the dense inverses out).
 // Operands of a tile product sit in LDS "k-major" ([k][m] and [k][n], row stride LDS_LD doubles), so that the 16x16x4 fragment
 // reads -- lane l takes element (k0 + l / 16, 16 w + l % 16) -- are contiguous per 16 lanes.
 #include <hip/hip_runtime.h>

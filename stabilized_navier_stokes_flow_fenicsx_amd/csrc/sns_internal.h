@@ -78,6 +78,7 @@ struct Level {
     // values per numeric setup straight into the level's low-precision format (k_lp_copies16 / k_ap_cvt32)
     int64_t ap_nnz = 0;
     int32_t *ap_rowptr = nullptr, *ap_colind = nullptr, *ap_ptr = nullptr, *ap_idx = nullptr;
+    int32_t* ap_colind_rep = nullptr;    // partitioned level right above the replicated tail's source: M's columns in the ids of the replicated level
     uint64_t* ap_nib = nullptr;          // per row: nibble j = the row-local M slot of block j (15: none); ~0 = row too long for k_lp_copies16's registers
     float* ap_vals32 = nullptr;
     void* ap_vals16 = nullptr;

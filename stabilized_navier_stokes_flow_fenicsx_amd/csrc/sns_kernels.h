@@ -53,15 +53,15 @@ template <int MODE, int FINE, int NT, int SPLIT>
 __global__ void k_spmv(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const double* vals,
                        const double* x, double* y, const double* bvec, const double* dinv, double omega,
                        const double* dotw, double* partial, const int32_t* row_list, const uint8_t* skip,
-                       int partial_off);
+                       int partial_off, GhostSrc gs);
 template <int MODE, int FINE, int SPLIT, int FMT, int UP = 1>
 __global__ void k_spmv_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
                           const float* scale, const double* x, double* y, const double* bvec, const float* dinv32,
-                          double omega, const int32_t* row_list, const uint8_t* skip);
+                          double omega, const int32_t* row_list, const uint8_t* skip, GhostSrc gs);
 template <int FMT, int FINE>
 __global__ void k_post_lp(int32_t n_rows, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                           const double* xc, const double* x_pre, const double* res1, const float* dinv32, double omega,
-                          const int32_t* agg, const uint8_t* free_mask, double* y);
+                          const int32_t* agg, const uint8_t* free_mask, double* y, GhostSrc gs);
 __global__ void k_ap_cvt32(int32_t n_rows, const int32_t* rowptr_m, const int32_t* colind_m, const int32_t* ap_ptr,
                            const int32_t* ap_idx, const double* vals_f, const int32_t* agg, const uint8_t* free_mask, float4* out);
 template <int WITH_M>
@@ -125,23 +125,24 @@ void dense_gj_inverse(hipStream_t s, hipStream_t side, int Np, double* A, double
 inline size_t dense_gj_work_doubles(int Np) { return (size_t)4 * 64 * Np + 4 * 4096; }
 // csrc/sns_block.hip: aggregate-block Jacobi smoother of the coarse levels (FMT = format of the level's matrix copy AND of the
 // aggregates' inverse blocks: 1 fp32, 2 fp16 with row scales)
-template <int FMT>
+template <int FMT, int GH = 0>
 __global__ void k_bsweep(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
-                         const float* scale, const void* binv, const double* x, double* y, const double* bvec, double omega);
-template <int FMT>
+                         const float* scale, const void* binv, const double* x, double* y, const double* bvec, double omega,
+                         GhostSrc gs);
+template <int FMT, int GH = 0>
 __global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
-                        const float* scale, const void* binv, const double* xc, const double* x_pre, const double* res1,
-                        double omega, const int32_t* agg, const uint8_t* free_mask, double* y);
+                        const float* scale, const void* binv, const double* xc, const double* xc_own, const double* x_pre,
+                        const double* res1, double omega, const int32_t* agg, const uint8_t* free_mask, double* y, GhostSrc gs);
 template <int FMT>
 __global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const void* binv, const double* bvec, double omega, double* z);
 template <int FMT>
 __global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                const uint8_t* free_mask, const double* r, double* bc, const void* binv_c, double omega_c, double* z_c);
-template <int FMT, int MODE>
+template <int FMT, int MODE, int GH = 0>
 __global__ void k_resid_restrict(int32_t nc, int32_t n_cslots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                  const uint8_t* free_mask, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                                  const double* x, const double* b, double* r_out, double* bc, const float* dinv32_c, const void* binv_c,
-                                 double omega_c, double* z_c);
+                                 double omega_c, double* z_c, GhostSrc gs);
 template <int FMT>
 __global__ void k_binv(int32_t nblk, const int32_t* blk_rows, const int32_t* blk_of, const int32_t* rowptr, const int32_t* colind,
                        const double* vals, void* binv, int* singular);

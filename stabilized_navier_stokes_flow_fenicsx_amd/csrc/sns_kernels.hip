@@ -1335,6 +1335,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 // SPLIT (multi-GPU, level 0): 0 = every row; 1 = interior pass: rows flagged in `skip` (rows with a ghost column)
 // are left alone, so the pass can run while the halo is still in flight; 2 = boundary pass over the n_rows rows
 // listed in `row_list`, after the halo has arrived.  partial_off: first partial-sum slot of this launch (AX_DOT).
+// SPLIT 3 (window transports, round 5): every row in ONE launch -- the ghost entries of x are read straight from the receive
+// window (`gs`, sns_peer_dev.h) and a wave that meets a ghost column waits for the neighbours' arrival flags itself: no unpack
+// kernel, no boundary launch, no second stream.  Rows without a ghost column never wait.
 template <int MODE, int FINE, int NT, int SPLIT>
 __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __restrict__ rowptr,
                                               const int32_t* __restrict__ colind,
@@ -1343,7 +1346,9 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
                                               const double* __restrict__ dinv, double omega,
                                               const double* __restrict__ dotw, double* __restrict__ partial,
                                               const int32_t* __restrict__ row_list,
-                                              const uint8_t* __restrict__ skip, int partial_off) {
+                                              const uint8_t* __restrict__ skip, int partial_off, GhostSrc gs) {
+    GhostReader gr;
+    if (SPLIT == 3) gr.begin(gs);
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1386,13 +1391,14 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
             double2 a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = (j < cnt) ? ld_stream(vp + 8 * j) : make_double2(0.0, 0.0);
+            if (SPLIT == 3) gr.arrive(gs, (c[0] >= gr.n_own) | (c[1] >= gr.n_own) | (c[2] >= gr.n_own) | (c[3] >= gr.n_own));
             double2 gA[4], gB[4];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int32_t cA = __builtin_amdgcn_mov_dpp(c[t4], 0x50, 0xF, 0xF, true);
                 const int32_t cB = __builtin_amdgcn_mov_dpp(c[t4], 0xFA, 0xF, 0xF, true);
-                gA[t4] = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cA + 2 * (jq & 1));
-                gB[t4] = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cB + 2 * (jq & 1));
+                gA[t4] = *reinterpret_cast<const double2*>((SPLIT == 3 ? gr.ptr(x, cA) : x + 4 * (int64_t)cA) + 2 * (jq & 1));
+                gB[t4] = *reinterpret_cast<const double2*>((SPLIT == 3 ? gr.ptr(x, cB) : x + 4 * (int64_t)cB) + 2 * (jq & 1));
             }
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
@@ -1423,8 +1429,9 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
                               a2 = (NT ? ld_stream(vp + 16) : vp[16]), a3 = (NT ? ld_stream(vp + 24) : vp[24]);
                 const int32_t cA = __builtin_amdgcn_mov_dpp(cme, 0x50, 0xF, 0xF, true);      // ids of blocks [0,0,1,1]
                 const int32_t cB = __builtin_amdgcn_mov_dpp(cme, 0xFA, 0xF, 0xF, true);      // ids of blocks [2,2,3,3]
-                const double2 gA = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cA + 2 * (jq & 1));
-                const double2 gB = *reinterpret_cast<const double2*>(x + 4 * (int64_t)cB + 2 * (jq & 1));
+                if (SPLIT == 3) gr.arrive(gs, cme >= gr.n_own);
+                const double2 gA = *reinterpret_cast<const double2*>((SPLIT == 3 ? gr.ptr(x, cA) : x + 4 * (int64_t)cA) + 2 * (jq & 1));
+                const double2 gB = *reinterpret_cast<const double2*>((SPLIT == 3 ? gr.ptr(x, cB) : x + 4 * (int64_t)cB) + 2 * (jq & 1));
                 // lane (.., hf) takes its pair from quad lane hf (block 0 / 2) or 2 + hf (block 1 / 3)
                 acc0 += a0.x * quad_perm<0x44>(gA.x) + a0.y * quad_perm<0x44>(gA.y);
                 acc1 += a1.x * quad_perm<0xEE>(gA.x) + a1.y * quad_perm<0xEE>(gA.y);
@@ -1435,7 +1442,9 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
         }
         for (; k < e; ++k) {
             const double2 a0 = (NT ? ld_stream(vp) : vp[0]);
-            const double g0 = x[4 * (int64_t)colind[k] + jq];
+            const int32_t ck = colind[k];
+            if (SPLIT == 3) gr.arrive(gs, ck >= gr.n_own);
+            const double g0 = (SPLIT == 3 ? gr.ptr(x, ck) : x + 4 * (int64_t)ck)[jq];
             acc0 += a0.x * quad_perm<0x88>(g0) + a0.y * quad_perm<0xDD>(g0);
             vp += 8;
         }
@@ -1476,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
 #define SNS_INST_SPMV(M, F, N, S)                                                                                  \
     template __global__ void k_spmv<M, F, N, S>(int32_t, const int32_t*, const int32_t*, const double*, const double*, \
                                                 double*, const double*, const double*, double, const double*, double*, \
-                                                const int32_t*, const uint8_t*, int);
+                                                const int32_t*, const uint8_t*, int, GhostSrc);
 SNS_INST_SPMV(SPMV_AX, 1, 1, 0)
 #ifdef SNS_HARNESS      // A/B variants of the experiment harness only (make HARNESS=1): not in the shipped library
 SNS_INST_SPMV(SPMV_AX, 1, 0, 0)
@@ -1498,6 +1507,10 @@ SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 1)
 SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 2)
 SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 1)
 SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 2)
+SNS_INST_SPMV(SPMV_AX, 1, 1, 3)
+SNS_INST_SPMV(SPMV_B_MINUS_AX, 1, 1, 3)
+SNS_INST_SPMV(SPMV_JACOBI, 1, 1, 3)
+SNS_INST_SPMV(SPMV_AX_DOT, 1, 1, 3)
 
 // Preconditioner passes with fp32 MATRIX VALUES (vectors, D^-1 and all arithmetic stay fp64):
 // the smoother / residual passes of the AMG cycle read a rounded copy of each level operator,
@@ -1545,7 +1558,9 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
                                                  double* __restrict__ y, const double* __restrict__ bvec,
                                                  const float* __restrict__ dinv, double omega,
                                                  const int32_t* __restrict__ row_list,
-                                                 const uint8_t* __restrict__ skip) {
+                                                 const uint8_t* __restrict__ skip, GhostSrc gs) {
+    GhostReader gr;                                               // SPLIT 3: ghost entries from the receive window (see k_spmv)
+    if (SPLIT == 3) gr.begin(gs);
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1595,10 +1610,16 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
                 P[q].x = o.x; P[q].y = o.y;
             }
         }
+        if (SPLIT == 3) {
+            bool gh = false;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) gh = gh | (c[t] >= gr.n_own);
+            gr.arrive(gs, gh);
+        }
         double2 xa[NS], xb[NS];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-            const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)c[t]);
+            const double2* xp = reinterpret_cast<const double2*>(SPLIT == 3 ? gr.ptr(x, c[t]) : x + 4 * (int64_t)c[t]);
             xa[t] = xp[0]; xb[t] = xp[1];
         }
 #pragma unroll
@@ -1618,7 +1639,8 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     for (; k + 3 < e; k += 4) {
         const int32_t cme = cnext;
         if (k + 7 < e) cnext = colind[k + 4 + r];
-        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        if (SPLIT == 3) gr.arrive(gs, cme >= gr.n_own);
+        const double2* xp = reinterpret_cast<const double2*>(SPLIT == 3 ? gr.ptr(x, cme) : x + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];                     // the whole x block of column (k + r)
         if (FMT == 1) {
             const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
@@ -1640,7 +1662,8 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
     if (k < e) {                                                  // 1..3 blocks left; quad-uniform
         const int32_t left = e - k;
         const int32_t cme = colind[k + (r < left ? r : 0)];
-        const double2* xp = reinterpret_cast<const double2*>(x + 4 * (int64_t)cme);
+        if (SPLIT == 3) gr.arrive(gs, cme >= gr.n_own);
+        const double2* xp = reinterpret_cast<const double2*>(SPLIT == 3 ? gr.ptr(x, cme) : x + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];
         if (FMT == 1) {
             acc0 += lp_dot(v32[0], quad_bcast2<0>(xa), quad_bcast2<0>(xb));
@@ -1675,15 +1698,17 @@ __global__ __launch_bounds__(256) void k_spmv_lp(int32_t n_rows, const int32_t* 
 #define SNS_INST_LP(M, F, S, T, U)                                                                                 \
     template __global__ void k_spmv_lp<M, F, S, T, U>(int32_t, const int32_t*, const int32_t*, const void*,           \
                                                       const float*, const double*, double*, const double*,           \
-                                                      const float*, double, const int32_t*, const uint8_t*);
+                                                      const float*, double, const int32_t*, const uint8_t*, GhostSrc);
 #define SNS_INST_LP_FMT(T)                   \
     SNS_INST_LP(SPMV_B_MINUS_AX, 1, 0, T, 1) \
     SNS_INST_LP(SPMV_B_MINUS_AX, 1, 1, T, 1) \
     SNS_INST_LP(SPMV_B_MINUS_AX, 1, 2, T, 1) \
+    SNS_INST_LP(SPMV_B_MINUS_AX, 1, 3, T, 1) \
     SNS_INST_LP(SPMV_B_MINUS_AX, 0, 0, T, 1) \
     SNS_INST_LP(SPMV_JACOBI, 1, 0, T, 1)     \
     SNS_INST_LP(SPMV_JACOBI, 1, 1, T, 1)     \
     SNS_INST_LP(SPMV_JACOBI, 1, 2, T, 1)     \
+    SNS_INST_LP(SPMV_JACOBI, 1, 3, T, 1)     \
     SNS_INST_LP(SPMV_JACOBI, 0, 0, T, 1)
 SNS_INST_LP_FMT(1)
 SNS_INST_LP_FMT(2)
@@ -1709,7 +1734,12 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
                                                  const double* __restrict__ x_pre, const double* __restrict__ res1,
                                                  const float* __restrict__ dinv, double omega,
                                                  const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
-                                                 double* __restrict__ y) {
+                                                 double* __restrict__ y, GhostSrc gs) {
+    // FINE 2: the fine level of a partitioned handle (window transports) -- the ghost aggregates' entries of xc come straight from
+    // the coarse level's receive window, the wave that meets one waits for the neighbours' flags itself (see k_spmv, SPLIT 3)
+    constexpr bool GH = FINE == 2;
+    GhostReader gr;
+    if (GH) gr.begin(gs);
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1749,10 +1779,11 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
                 P[q].x = o.x; P[q].y = o.y;
             }
         }
+        if (GH) gr.arrive(gs, (c[0] >= gr.n_own) | (c[1] >= gr.n_own));
         double2 xa[NS], xb[NS];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-            const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)c[t]);
+            const double2* xp = reinterpret_cast<const double2*>(GH ? gr.ptr(xc, c[t]) : xc + 4 * (int64_t)c[t]);
             xa[t] = xp[0]; xb[t] = xp[1];
         }
 #pragma unroll
@@ -1768,7 +1799,8 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
     }
     for (; k + 3 < e; k += 4) {                                   // longer rows (coarse levels, unstructured meshes)
         const int32_t cme = colind[k + r];
-        const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)cme);
+        if (GH) gr.arrive(gs, cme >= gr.n_own);
+        const double2* xp = reinterpret_cast<const double2*>(GH ? gr.ptr(xc, cme) : xc + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];
         if (FMT == 1) {
             const float4 a0 = v32[0], a1 = v32[4], a2 = v32[8], a3 = v32[12];
@@ -1790,7 +1822,8 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
     if (k < e) {                                                  // 1..3 blocks left; quad-uniform
         const int32_t left = e - k;
         const int32_t cme = colind[k + (r < left ? r : 0)];
-        const double2* xp = reinterpret_cast<const double2*>(xc + 4 * (int64_t)cme);
+        if (GH) gr.arrive(gs, cme >= gr.n_own);
+        const double2* xp = reinterpret_cast<const double2*>(GH ? gr.ptr(xc, cme) : xc + 4 * (int64_t)cme);
         const double2 xa = xp[0], xb = xp[1];
         if (FMT == 1) {
             acc0 += lp_dot(v32[0], quad_bcast2<0>(xa), quad_bcast2<0>(xb));
@@ -1821,8 +1854,8 @@ __global__ __launch_bounds__(256, 6) void k_post_lp(int32_t n_rows, const int32_
 #define SNS_INST_POST(T, F)                                                                                        \
     template __global__ void k_post_lp<T, F>(int32_t, const int32_t*, const int32_t*, const void*, const float*,   \
                                              const double*, const double*, const double*, const float*, double,   \
-                                             const int32_t*, const uint8_t*, double*);
-SNS_INST_POST(1, 0) SNS_INST_POST(1, 1) SNS_INST_POST(2, 0) SNS_INST_POST(2, 1)
+                                             const int32_t*, const uint8_t*, double*, GhostSrc);
+SNS_INST_POST(1, 0) SNS_INST_POST(1, 1) SNS_INST_POST(2, 0) SNS_INST_POST(2, 1) SNS_INST_POST(1, 2) SNS_INST_POST(2, 2)
 
 // M = A P for the fused post-smoothing sweep in fp32 (amg_f32_matrix = 1; the fp16 format is written by k_lp_copies16 below):
 // M slot (i, J) <- sum of the fine blocks (i, j), j in aggregate J (gather list ap_ptr / ap_idx, fixed order), no fp64 copy of M
@@ -2189,24 +2222,27 @@ __global__ __launch_bounds__(256) void k_reduce_final_bicg_peer(int nblocks, con
     constexpr int NRED = WHICH == 1 ? 1 : 5;
     __shared__ double red[NRED][256];
     __shared__ double tot[8];
-    double s[NRED];
+    if (pa.phase != 2) {                           // (team transport: phase 1 = reduce + contribute, phase 2 = sum + update)
+        double s[NRED];
 #pragma unroll
-    for (int k = 0; k < NRED; ++k) s[k] = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < NRED; ++k) s[k] = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
 #pragma unroll
-        for (int k = 0; k < NRED; ++k) s[k] += partial[(int64_t)b * NRED + k];
+            for (int k = 0; k < NRED; ++k) s[k] += partial[(int64_t)b * NRED + k];
 #pragma unroll
-    for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] = s[k];
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
+        for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] = s[k];
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o)
 #pragma unroll
-            for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+                for (int k = 0; k < NRED; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x < NRED) tot[threadIdx.x] = red[threadIdx.x][0];
         __syncthreads();
     }
-    if (threadIdx.x < NRED) tot[threadIdx.x] = red[threadIdx.x][0];
-    __syncthreads();
     peer_allreduce_block(tot, NRED, pa);
+    if (pa.phase == 1) return;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NRED; ++k) red_out[k] = tot[k];

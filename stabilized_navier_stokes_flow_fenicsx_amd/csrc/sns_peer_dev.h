@@ -1,11 +1,19 @@
-// Device side of the peer-window transport (sns_comm.h): the control area every rank exposes to its peers and the
-// store / flag / bounded-wait primitives the collective kernels are made of.  Header-only so that a solver kernel can carry a
-// collective inside it (k_reduce_final_bicg_peer: final reduction stage + all-reduce + scalar update in one launch).
+// Device side of the peer-window transport (sns_comm.h): the control area every rank exposes to its peers, the
+// store / flag / bounded-wait primitives the collective kernels are made of, and the descriptor a solver kernel takes to read the
+// ghost entries of its input vector STRAIGHT from the receive window (GhostSrc).  Header-only so that a solver kernel can carry a
+// collective inside it (k_reduce_final_bicg_peer: final reduction stage + all-reduce + scalar update in one launch; the level
+// passes of a partitioned handle: wait for the neighbours' halo inside the pass itself).
 //
 // Memory model: the windows are fine-grained device memory.  A sender's payload stores are followed by a system-scope fence and
-// a system-scope release store of a sequence number; a receiver polls that number with system-scope acquire loads and reads the
-// payload with system-scope loads, never through a cache line left from an earlier round.  Every wait is bounded and reports
-// through a host-mapped error word instead of spinning for ever.
+// a system-scope release store of a sequence number.  A receiver polls that number with system-scope acquire loads, then EVERY
+// lane of the wave executes a system-scope acquire fence (which invalidates whatever the caches of this GPU still hold of the
+// window from an earlier round) and reads the payload with plain loads issued after the fence.  Nothing reads a receive buffer of
+// round s before it has seen the flags of ALL its neighbours for round s, so no cache line of that buffer can be (re)filled
+// between the fence and the data's arrival.  Every wait is bounded and reports through a host-mapped error word instead of
+// spinning for ever.
+//
+// Sequence numbers live in DEVICE memory and are advanced by the kernels themselves (the put raises its plan's round, the
+// consumer reads it): no kernel argument changes from one round to the next, so a whole solver iteration can be a hipGraph.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,11 +32,29 @@ struct PeerCtl {
 };
 
 struct PeerArgs {                                // what a kernel needs to take part in an all-reduce
-    unsigned long long seq;
+    unsigned long long* seq;                     // device word of THIS rank: rounds completed; the kernel runs round *seq + 1
     int rank, nranks;
     PeerCtl* const* ctl;                         // device array [nranks]: every rank's control area (own included)
     int* err;
     long long timeout_ticks;                     // wall_clock64() ticks (100 MHz)
+    int phase;                                   // 0: the whole collective in this launch (flags + waits);  in-process team
+                                                 // transport (the ranks' kernels are serialised on one queue, the host barrier
+                                                 // stands in for the flags): 1 = contribute only, 2 = sum only
+};
+
+// Where a pass over a partitioned level finds the ghost entries of its input vector: node j >= n_own of the vector lives at
+// win[parity] + 4 * j (the pointers are pre-offset by -4 * n_own doubles: the receive buffer holds the ghost nodes in their
+// local order), parity = *seq & 1 with *seq the plan's round as left by the put kernel in front of this pass.  nn > 0: the wave
+// that meets its first ghost column waits (bounded) for the nn neighbours' arrival flags of that round.  win[0] == nullptr: no
+// window -- the ghost entries sit in the vector's own tail (serial handles, RCCL).
+struct GhostSrc {
+    const double* win[2] = {nullptr, nullptr};
+    int32_t n_own = 0x7fffffff;
+    int nn = 0;
+    const unsigned long long* seq = nullptr;
+    const unsigned long long* flag = nullptr;
+    int* err = nullptr;
+    long long timeout_ticks = 0;
 };
 
 __device__ __forceinline__ void peer_flag_store(unsigned long long* f, unsigned long long v) {
@@ -52,29 +78,71 @@ __device__ __forceinline__ double peer_sys_load(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The ghost side of a pass, per wave: `begin` reads the round once (uniform), `ptr` selects the source of a column's x block,
+// `arrive` is called (by all active lanes of the wave, any control flow) before the first ghost entry is read.
+struct GhostReader {
+    const double* xg;                            // pre-offset receive buffer of this round (nullptr: no window)
+    int32_t n_own;
+    unsigned long long sq;
+    bool waited;
+    __device__ __forceinline__ void begin(const GhostSrc& g) {
+        n_own = g.n_own;
+        xg = nullptr;
+        sq = 0ull;
+        waited = true;
+        if (g.win[0]) {
+            sq = *g.seq;
+            xg = g.win[sq & 1ull];
+            waited = g.nn == 0;
+        }
+    }
+    __device__ __forceinline__ const double* ptr(const double* x, int32_t col) const {
+        return (col >= n_own ? xg : x) + 4 * (int64_t)col;
+    }
+    // any: does some lane of this wave need a ghost entry now?  (lanes vote with their own column ids)
+    __device__ __forceinline__ void arrive(const GhostSrc& g, bool mine_is_ghost) {
+        if (waited) return;
+        if (!__any(mine_is_ghost)) return;
+        // (every active lane polls every flag -- same address, one request per wave: the lanes that are active here may be any)
+        for (int k = 0; k < g.nn; ++k) (void)peer_flag_wait(g.flag + k, sq, g.timeout_ticks, g.err, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");         // every lane: nothing older than the flags is read below
+        waited = true;
+    }
+};
+
 // Sum v[0..count) over the ranks, result back in v (workgroup-shared or global memory; count <= PEER_AR_MAX).  Called by ALL
 // threads of one workgroup of >= max(nranks, count) threads.  Contribution into every rank's slot table, flags, wait for
-// everybody's, sum in rank order: the same bits on every rank.  Slots are double-buffered by the parity of seq: a rank can start
-// round s + 2 only after round s + 1 completed, i.e. after every rank has contributed to s + 1, which each did after reading s.
+// everybody's, sum in rank order: the same bits on every rank.  Slots are double-buffered by the parity of the round: a rank can
+// start round s + 2 only after round s + 1 completed, i.e. after every rank has contributed to s + 1, which each did after reading s.
+// a.phase 1 / 2 (team transport): the two halves as separate launches with a host barrier between them.
 __device__ __forceinline__ void peer_allreduce_block(double* v, int count, const PeerArgs& a) {
-    const int tid = threadIdx.x, nth = blockDim.x, par = (int)(a.seq & 1ull);
-    for (int idx = tid; idx < a.nranks * count; idx += nth) {
-        const int r = idx / count, i = idx - r * count;
-        a.ctl[r]->ar_slot[par][a.rank][i] = v[i];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const unsigned long long seq = *a.seq + 1ull;
+    const int par = (int)(seq & 1ull);
+    if (a.phase != 2) {
+        for (int idx = tid; idx < a.nranks * count; idx += nth) {
+            const int r = idx / count, i = idx - r * count;
+            a.ctl[r]->ar_slot[par][a.rank][i] = v[i];
+        }
     }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < a.nranks) {
-        peer_flag_store(&a.ctl[tid]->ar_flag[a.rank], a.seq);
-        (void)peer_flag_wait(&a.ctl[a.rank]->ar_flag[tid], a.seq, a.timeout_ticks, a.err, 2);
+    if (a.phase == 1) return;
+    if (a.phase == 0) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid < a.nranks) {
+            peer_flag_store(&a.ctl[tid]->ar_flag[a.rank], seq);
+            (void)peer_flag_wait(&a.ctl[a.rank]->ar_flag[tid], seq, a.timeout_ticks, a.err, 2);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
-    __syncthreads();
     if (tid < count) {
         double s = 0.0;
         for (int r = 0; r < a.nranks; ++r) s += peer_sys_load(&a.ctl[a.rank]->ar_slot[par][r][tid]);
         v[tid] = s;
     }
     __syncthreads();
+    if (tid == 0) *a.seq = seq;
 }
 
 }  // namespace sns

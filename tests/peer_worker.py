@@ -33,8 +33,9 @@ def main():
     peers = None
     try:
         torch.cuda.set_device(0)
-        peers = PeerGroup(device="cuda:0", window_bytes=16 << 20)
+        peers = PeerGroup(device="cuda:0", window_bytes=16 << 20, check_rounds=int(os.environ.get("SNS_TEST_CHECK_ROUNDS", "50")))
         kw = {}
+        kw_env = json.loads(os.environ.get("SNS_TEST_OPTS", "{}"))          # (tests: option sets of the partitioned path)
         if kind.startswith("duct"):
             m = M.duct_mesh((24, 6, 6), 4.0, jitter=0.1)
             bcs = B.duct_bcs(m)
@@ -55,6 +56,7 @@ def main():
         Us, ws = Us.cpu().numpy(), ws.cpu().numpy()
         Ps.close()
 
+        kw.update(kw_env)
         P = FlowProblem.distributed(m, (mask, g), group=peers, reynolds=Re, **kw)
         info = P.comm_info()
         part = P.part
@@ -74,7 +76,7 @@ def main():
                 out.update(ok=True, transport=info["transport"], nranks=info["nranks"], stokes_its=r.its, stokes_reason=r.reason,
                            newton_its=n.its, newton_reason=n.reason, ksp_its=list(n.ksp_its) if hasattr(n.ksp_its, "__iter__") else n.ksp_its,
                            serial=dict(stokes_its=rs.its, newton_its=ns.its, newton_reason=ns.reason),
-                           err_stokes=rel(Ug, Us), err_newton=rel(wg, ws), err_spmv=rel(yg, ys),
+                           err_stokes=rel(Ug, Us), err_newton=rel(wg, ws), err_spmv=rel(yg, ys), stokes_rnorm=r.rnorm,
                            levels=P.timings().amg_levels, cycle=[(x["kind"], x["pre"], x["post"]) for x in P.cycle()], exchanges=c.get("exchanges"), allreduces=c.get("allreduces"),
                            n_owned=int(part.n_owned), neighbors=[int(v) for v in part.neighbors], seconds=time.time() - t0)
             except SnsError as e:

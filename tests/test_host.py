@@ -155,6 +155,10 @@ def test_struct_layouts_match_the_header(tmp_path):
     stub = re.search(r"class SnsOptions\(C\.Structure\):(.*?)\n\n", integ, flags=re.S)
     assert stub, "INTEGRATION.md lost its SnsOptions stub"
     assert re.findall(r'\("([a-z0-9_]+)",', stub.group(1)) == structs["sns_options"]
+    # ... and guards the ABI version of the header it was written against (the stub once refused the shipped library)
+    abi_hdr = int(re.search(r"#define SNS_ABI_VERSION (\d+)", hdr).group(1))
+    abi_stub = re.search(r"sns\.sns_abi_version\(\) == (\d+)", integ)
+    assert abi_stub and int(abi_stub.group(1)) == abi_hdr == _lib.ABI_VERSION
 
 
 def test_host_pattern_matches_scipy(built_lib):
