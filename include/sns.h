@@ -28,6 +28,13 @@
 
 #include <stdint.h>
 
+/* libsns.so is built with -fvisibility=hidden: the dynamic symbol table holds exactly the functions declared below */
+#if defined(__GNUC__) || defined(__clang__)
+#define SNS_API __attribute__((visibility("default")))
+#else
+#define SNS_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -215,16 +222,16 @@ typedef struct {
                                cycle).  0, and always over RCCL (an exchange per sweep costs a send / recv group there): round 4's cycle */
 } sns_options;
 
-void sns_default_options(sns_options* opt);
-const char* sns_last_error(void);
-const char* sns_version(void);
+SNS_API void sns_default_options(sns_options* opt);
+SNS_API const char* sns_last_error(void);
+SNS_API const char* sns_version(void);
 /* ABI guard (round 4): the library's SNS_ABI_VERSION and sizeof(sns_options).  sns_options grows at its END between rounds
  * and the fixed-size out-arrays of the getters below have grown (sns_get_counters / sns_get_kernel_times: 4 -> 8 entries in
  * round 3), so a binding built against an older header would pass short buffers: bindings compare both numbers with the
  * header they were written against before making any other call (the ctypes mirror does, _lib.py) and refuse on a mismatch. */
 #define SNS_ABI_VERSION 6
-int sns_abi_version(void);
-int64_t sns_options_size(void);
+SNS_API int sns_abi_version(void);
+SNS_API int64_t sns_options_size(void);
 
 /* ---- setup: replaces gmshio.model_to_mesh + functionspace + create_matrix +
  *      locate_dofs_topological/dirichletbc (:111,:127-147,:271-272) ----------
@@ -233,7 +240,7 @@ int64_t sns_options_size(void);
  * bc_mask_host [4*n_nodes]   1 where the dof is Dirichlet-constrained
  * bc_val_host  [4*n_nodes]   prescribed value g (ignored where mask==0)
  * device       HIP device ordinal                                              */
-int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets,
+SNS_API int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets,
                const double* points_host, const int32_t* tets_host,
                const uint8_t* bc_mask_host, const double* bc_val_host,
                int device, const sns_options* opt);
@@ -244,17 +251,17 @@ int sns_create(sns_handle* out, int32_t n_nodes, int64_t n_tets,
  * form with (stokes_viscosity, stokes_beta) and SNS_FORM_NS the P1-P1 form with the h-based Tezduyar UGN
  * tau_SUPG / tau_LSIC (LidDrivenNavierStokesFlow.py:123-143 == DFG_2D_Validation.py:141-163) and its exact Gateaux
  * derivative; every other entry point works unchanged.  Single GPU only (no sns_attach_comm).                    */
-int sns_create_2d(sns_handle* out, int32_t n_nodes, int64_t n_tris,
+SNS_API int sns_create_2d(sns_handle* out, int32_t n_nodes, int64_t n_tris,
                   const double* points_host, const int32_t* tris_host,
                   const uint8_t* bc_mask_host, const double* bc_val_host,
                   int device, const sns_options* opt);
-int sns_destroy(sns_handle h);
-int sns_set_stream(sns_handle h, void* hip_stream);
-int sns_set_options(sns_handle h, const sns_options* opt);
-int sns_get_options(sns_handle h, sns_options* opt);
+SNS_API int sns_destroy(sns_handle h);
+SNS_API int sns_set_stream(sns_handle h, void* hip_stream);
+SNS_API int sns_set_options(sns_handle h, const sns_options* opt);
+SNS_API int sns_get_options(sns_handle h, sns_options* opt);
 
 /* sizes: n_owned = rows this rank owns, n_local = owned + ghost nodes */
-int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,
+SNS_API int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,
                   int64_t* n_tets, int64_t* nnz_blocks);
 
 /* ---- distributed setup (one process per GPU; RCCL over xGMI) ---------------
@@ -267,8 +274,8 @@ int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,
  * the caller (torch.distributed).  NULL = no communicator: the handle only
  * learns its owned/ghost split and the caller moves ghost values itself
  * (single-GPU tests of the partitioned path).                                  */
-int sns_comm_unique_id(char id_out[128]);
-int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_id[128],
+SNS_API int sns_comm_unique_id(char id_out[128]);
+SNS_API int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_id[128],
                     int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
@@ -278,9 +285,9 @@ int sns_attach_comm(sns_handle h, int rank, int nranks, const char nccl_unique_i
  * barriers and device copies so the N-rank algorithm can be verified on a 1-GPU box.
  * Every rank (thread) attaches its own handle; all collective calls must then be made
  * concurrently from the N threads.  Never used by bench.py or the drivers.          */
-int sns_team_create(int nranks, void** team_out);
-int sns_team_destroy(void* team);
-int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
+SNS_API int sns_team_create(int nranks, void** team_out);
+SNS_API int sns_team_destroy(void* team);
+SNS_API int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
                     int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
@@ -294,40 +301,46 @@ int sns_attach_team(sns_handle h, void* team, int rank, int nranks,
  *   sns_peer_connect : ipc_handles = nranks x 64 bytes in rank order (all-gathered by the caller, e.g. torch.distributed);
  *                      call on every rank, then synchronise the ranks once before the first attach
  *   sns_attach_peer  : as sns_attach_comm (same plan arguments; rank / nranks are the communicator's); collective
- *   sns_peer_destroy : after every handle attached to it is destroyed AND the ranks have synchronised
+ *   sns_peer_disconnect : first half of the teardown, after every handle attached to the communicator is destroyed AND the ranks
+ *                      have synchronised: unmaps the other ranks' windows.  Synchronise the ranks once more, then
+ *   sns_peer_destroy : frees this rank's window (no peer has it mapped any more: the HIP IPC contract leaves freeing a
+ *                      still-mapped allocation undefined).  Without a preceding sns_peer_disconnect it does both halves at once
  * At most 16 ranks.  Every device-side wait is bounded (SNS_PEER_TIMEOUT_MS, default 20000): a late or dead peer turns into
  * SNS_E_COMM at the next host synchronisation instead of a hang.                                                          */
-int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]);
-int sns_peer_connect(void* peer, const char* ipc_handles);
-int sns_peer_destroy(void* peer);
+SNS_API int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void** peer_out, char ipc_handle_out[64]);
+SNS_API int sns_peer_connect(void* peer, const char* ipc_handles);
+SNS_API int sns_peer_disconnect(void* peer);
+SNS_API int sns_peer_destroy(void* peer);
 /* Link check between the REAL ranks of a connected communicator (collective, after sns_peer_connect and one synchronisation of the
- * ranks): `rounds` all-reduces whose contributions depend on rank and round and `rounds` all-gathers of 4096 patterned doubles per rank,
- * every value verified.  The first thing to run on a new machine: a visibility problem of the windows shows up here as SNS_E_COMM with
- * a count instead of as a solve that quietly diverges.                                                                              */
-int sns_peer_check_links(void* peer, int rounds);
+ * ranks): `rounds` all-reduces whose contributions depend on rank and round, `rounds` all-gathers of 4096 patterned doubles per rank
+ * and `rounds` halo exchanges over a ring between the ranks (2048 nodes per direction; read alternately through the wait / unpack
+ * kernel and through the level passes' own path: the wait inside the consumer, the ghost entries straight from the window), every
+ * value verified.  The first thing to run on a new machine: a visibility problem of the windows shows up here as SNS_E_COMM with a
+ * count instead of as a solve that quietly diverges.                                                                              */
+SNS_API int sns_peer_check_links(void* peer, int rounds);
 /* Self-test and latency probe of the protocol inside ONE process: nranks (2 or 3) threads with a window, a stream and a
  * communicator end each, wired directly (no IPC), a ring of halo links of `halo_nodes` nodes per direction.  Per collective -- halo
  * exchange, all-reduce (4 doubles), all-gather (2048 doubles per rank) -- `reps` rounds with every payload verified, then `reps`
  * timed rounds of the collective alone: us_out = microseconds per round (max over ranks); then three verified rounds of the long forms
  * (an all-reduce of 40 doubles = two launches, an all-gather of more than three staging chunks).  SNS_E_COMM on a wrong value or a timeout. */
-int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
-int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
+SNS_API int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]);
+SNS_API int sns_attach_peer(sns_handle h, void* peer, int32_t n_owned_nodes, int n_neighbors, const int32_t* neighbor_ranks,
                     const int32_t* send_ptr, const int32_t* send_idx,
                     const int32_t* recv_ptr, const int32_t* recv_idx);
 
 /* ---- hot path --------------------------------------------------------------*/
 /* NonlinearPDE_SNESProblem.F (:51-67): F(w) incl. lifting and F_B = w_B - g.
  * form = SNS_FORM_NS, or SNS_FORM_STOKES for the linear residual A w - b.     */
-int sns_residual(sns_handle h, int form, const double* w_dev, double* F_dev);
+SNS_API int sns_residual(sns_handle h, int form, const double* w_dev, double* F_dev);
 /* NonlinearPDE_SNESProblem.J (:69-75): assemble the Jacobian (BC rows+cols
  * zeroed, unit diagonal) into the handle's BSR matrix; if F_dev != NULL the
  * residual is produced by the same fused element pass.                        */
-int sns_jacobian(sns_handle h, int form, const double* w_dev, double* F_dev);
+SNS_API int sns_jacobian(sns_handle h, int form, const double* w_dev, double* F_dev);
 /* MatMult with the assembled operator: y = A x (halo exchange inside).        */
-int sns_spmv(sns_handle h, const double* x_dev, double* y_dev);
+SNS_API int sns_spmv(sns_handle h, const double* x_dev, double* y_dev);
 /* PCSetUp / PCApply for the current matrix.                                   */
-int sns_pc_setup(sns_handle h);
-int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
+SNS_API int sns_pc_setup(sns_handle h);
+SNS_API int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
 /* KSPSolve: A x = b with the handle's ksp/pc options; x_dev holds the initial
  * guess on entry.  rnorm = 2-norm of the TRUE residual b - A x at exit.  With
  * amg_retry_damping (default on) a solve that ends in DIVERGED_BREAKDOWN or
@@ -337,23 +350,23 @@ int sns_pc_apply(sns_handle h, const double* r_dev, double* z_dev);
  * sns_set_options.  *its then counts both attempts (<= 2 ksp_max_it), *reason is the
  * last attempt's, the first attempt's is out[6] of sns_get_counters.  Running out of
  * iterations (DIVERGED_ITS) is never retried.                                    */
-int sns_krylov_solve(sns_handle h, const double* b_dev, double* x_dev,
+SNS_API int sns_krylov_solve(sns_handle h, const double* b_dev, double* x_dev,
                      int* its, int* reason, double* rnorm);
 /* solve_stokes_problem (:197-218): assemble + lift + KSP; U_dev receives U.   */
-int sns_stokes_solve(sns_handle h, double* U_dev, int* ksp_its, int* reason, double* rnorm);
+SNS_API int sns_stokes_solve(sns_handle h, double* U_dev, int* ksp_its, int* reason, double* rnorm);
 /* solve_navier_stokes (:268-312): SNES newtonls + bt; w_dev updated in place
  * (snes.solve(None, w) :293).  fnorm_hist (nullable) gets ||F|| per iteration
  * (snes_monitor :276), at most hist_cap entries.                              */
-int sns_newton_solve(sns_handle h, double* w_dev, int* its, int* reason,
+SNS_API int sns_newton_solve(sns_handle h, double* w_dev, int* its, int* reason,
                      int* total_ksp_its, double* fnorm_hist, int hist_cap);
 
 /* ---- introspection (tests, profiling) --------------------------------------*/
 /* device pointers of the assembled BSR4 operator (block row-major 4x4)        */
-int sns_get_bsr(sns_handle h, int32_t* n_rows, int64_t* nnzb, const int32_t** rowptr_dev,
+SNS_API int sns_get_bsr(sns_handle h, int32_t* n_rows, int64_t* nnzb, const int32_t** rowptr_dev,
                 const int32_t** colind_dev, const double** vals_dev);
 /* element-level output of the last sns_jacobian call: Ke [n_tets][a][b][c][d]
  * (16 blocks of 4x4) as produced by the element kernel before the gather.     */
-int sns_get_element_scratch(sns_handle h, const double** Ke_dev, const double** Fe_dev);
+SNS_API int sns_get_element_scratch(sns_handle h, const double** Ke_dev, const double** Fe_dev);
 /* copy an internal device array into a caller-owned device buffer of nbytes
  * (exact size required): tests read the assembled operator through this.      */
 #define SNS_EXPORT_ROWPTR 0   /* int32 [n_local+1]        */
@@ -361,31 +374,31 @@ int sns_get_element_scratch(sns_handle h, const double** Ke_dev, const double** 
 #define SNS_EXPORT_VALS   2   /* double [nnzb*16]         */
 #define SNS_EXPORT_KE     3   /* double [n_tets*256]      */
 #define SNS_EXPORT_FE     4   /* double [n_tets*16]       */
-int sns_export(sns_handle h, int what, void* dst_dev, int64_t nbytes);
+SNS_API int sns_export(sns_handle h, int what, void* dst_dev, int64_t nbytes);
 /* timing of the phases of the last solve, milliseconds (HIP events)           */
 typedef struct {
     double assemble_ms, pc_setup_ms, krylov_ms, spmv_ms_avg;
     int64_t spmv_calls; int ksp_its; int amg_levels;
 } sns_timings;
-int sns_get_timings(sns_handle h, sns_timings* t);
+SNS_API int sns_get_timings(sns_handle h, sns_timings* t);
 /* debug counters of the LAST Krylov solve: out[0] = host<->device synchronisations (stream / event waits),
  * out[1] = all-reduces, out[2] = neighbour (halo) exchanges; out[3] = Krylov iterations since reset_timings,
  * out[4] = damping retries since reset_timings, out[5] = current damping factor x 1e6 (1000000 = no retry so far),
  * out[6] = reason of the first attempt of the last solve if it was retried (else 0), out[7] = blocks of the fine level's
  * M = A P (fused post-smoothing sweep; 0 until the hierarchy exists) */
-int sns_get_counters(sns_handle h, int64_t out[8]);
+SNS_API int sns_get_counters(sns_handle h, int64_t out[8]);
 /* communicator of the handle: out[0] = transport (0 none, 1 RCCL, 2 in-process team, 3 peer windows), out[1] = this rank,
  * out[2] = ranks the handle was attached with, out[3] = ranks RCCL itself reports (ncclCommCount; 0 without RCCL):
  * bench.py prints it so that "did RCCL see N ranks" can be read off the result line */
-int sns_comm_info(sns_handle h, int32_t out[4]);
+SNS_API int sns_comm_info(sns_handle h, int32_t out[4]);
 /* the AMG hierarchy as built (what PETSc's -ksp_view prints of a PCGAMG/PCMG): *nlevels levels (at most 16 reported; a
  * partitioned handle counts its replicated tail copy), per level the rows this rank solves for, the 4x4 blocks of its
  * operator, the sweeps per half cycle level_nu gives it (after amg_nu_scale_with_size) and the block-Jacobi damping in use */
-int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t blocks[16], int32_t sweeps[16], double omega[16]);
+SNS_API int sns_get_hierarchy(sns_handle h, int32_t* nlevels, int64_t rows[16], int64_t blocks[16], int32_t sweeps[16], double omega[16]);
 /* the dense coarsest-level solver on its own (tests): Ainv_dev <- inverse of the N x N row-major fp64 matrix A_dev by the blocked
  * Gauss-Jordan elimination of csrc/sns_dense.hip (64 x 64 blocks, v_mfma_f64_16x16x4_f64 rank-64 updates, NO pivoting: meant for
  * matrices whose symmetric part is positive definite, like the level operators).  SNS_E_STATE on a zero / non-finite pivot. */
-int sns_dense_inverse(int device, int32_t N, const double* A_dev, double* Ainv_dev);
+SNS_API int sns_dense_inverse(int device, int32_t N, const double* A_dev, double* Ainv_dev);
 /* the V-cycle as run: per level the smoother / solver kind and the sweeps before and after the coarse-grid correction (the
  * first pre-sweep starts from the zero guess).  Tests restate the cycle from this (oracle/amg_cycle.py).                    */
 #define SNS_LEVEL_NODAL_BLOCKS      0   /* damped Jacobi with the 4 x 4 nodal blocks                                         */
@@ -393,22 +406,22 @@ int sns_dense_inverse(int device, int32_t N, const double* A_dev, double* Ainv_d
 #define SNS_LEVEL_DIRECT            2   /* coarsest level: dense inverse by the one-workgroup Gauss-Jordan with pivoting     */
 #define SNS_LEVEL_DIRECT_BLOCKED    3   /* coarsest level: dense inverse by the blocked Gauss-Jordan of csrc/sns_dense.hip   */
 #define SNS_LEVEL_SWEEPS_ONLY       4   /* coarsest level too large for a direct solve: 1 + 8 nodal-block sweeps              */
-int sns_get_cycle(sns_handle h, int32_t* nlevels, int32_t kind[16], int32_t nu_pre[16], int32_t nu_post[16]);
-int sns_reset_timings(sns_handle h);
+SNS_API int sns_get_cycle(sns_handle h, int32_t* nlevels, int32_t kind[16], int32_t nu_pre[16], int32_t nu_post[16]);
+SNS_API int sns_reset_timings(sns_handle h);
 /* per-launch HIP-event timing of the level-0 k_spmv family inside solves
  * (index = mode: 0 y=Ax, 1 r=b-Ax, 2 Jacobi sweep, 3 y=Ax with fused dot,
  *  4 fused correction + post-sweep on M = A P; 5..7 reserved)                  */
-int sns_time_kernels(sns_handle h, int on);
-int sns_get_kernel_times(sns_handle h, double ms_total[8], int64_t calls[8]);
+SNS_API int sns_time_kernels(sns_handle h, int on);
+SNS_API int sns_get_kernel_times(sns_handle h, double ms_total[8], int64_t calls[8]);
 /* raw kernel launchers for micro-benchmarks (bench.py roofline leg): run the
  * kernel `reps` times between two HIP events on the handle's stream and return
  * the average duration in ms.                                                  */
-int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
-int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
+SNS_API int sns_bench_spmv(sns_handle h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
+SNS_API int sns_bench_assemble(sns_handle h, int form, const double* w_dev, double* F_dev, int reps, double* ms_avg);
 /* one collective of the attached communicator, `reps` times back to back (COLLECTIVE: every rank calls it with the same arguments):
  * which 0 = halo exchange of the assembled operator's plan, 1 = all-reduce of `count` (1..32) doubles, 2 = all-gather of `count`
  * doubles per rank.  Any transport.                                                                                          */
-int sns_bench_collective(sns_handle h, int which, int count, int reps, double* ms_avg);
+SNS_API int sns_bench_collective(sns_handle h, int which, int count, int reps, double* ms_avg);
 /* ---- batched particle tracing (next row after the solve path; replaces the per-seed
  *      solve_ivp(RK45) of NavierStokes/streamtrace.py:208-232, :357-383) ---------------
  * One lane per seed: scipy's RK45 (same tableau, controller and initial step; rtol/atol as
@@ -419,7 +432,7 @@ int sns_bench_collective(sns_handle h, int which, int count, int reps, double* m
  * or downward (reverse, 0.13 :185-188) -> status 2; t_end reached -> 0; step underflow -> 3.
  * nbr_dev[4t+a] = tet across the face opposite local vertex a of tet t, -1 on the boundary;
  * seed_tet_dev = a tet containing (or near) each seed.  All pointers are device memory.   */
-int sns_streamtrace(int32_t n_nodes, int64_t n_tets, const double* pts_dev, const int32_t* tets_dev,
+SNS_API int sns_streamtrace(int32_t n_nodes, int64_t n_tets, const double* pts_dev, const int32_t* tets_dev,
                     const int32_t* nbr_dev, const double* vel_dev, int32_t n_seeds,
                     const double* seeds_dev, const int32_t* seed_tet_dev, int reverse, double t_end,
                     double max_step, double rtol, double atol, double x_stop, double speed_min,
@@ -431,24 +444,24 @@ int sns_streamtrace(int32_t n_nodes, int64_t n_tets, const double* pts_dev, cons
  * BSR sparsity pattern of the P1-P1 operator (what create_matrix derives from
  * the dofmap, :272) and the slot -> element-block gather lists of the
  * atomic-free assembly.  Call with NULL outputs to query sizes.               */
-int sns_host_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets_host,
+SNS_API int sns_host_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tets_host,
                      int64_t* nnzb_out,
                      int32_t* rowptr_out /*n_nodes+1*/, int32_t* colind_out /*nnzb*/,
                      int64_t* c_ptr_out /*nnzb+1*/, int32_t* c_idx_out /*16*n_tets*/);
 /* size-limited greedy aggregation of the first n_active nodes of a pattern;
  * agg_out[n_nodes] gets the aggregate id (-1 for inactive nodes).             */
-int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind,
+SNS_API int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind,
                        int32_t n_active, int max_agg, int32_t* agg_out, int32_t* n_agg_out);
 
 /* owned rows (i < n_owned) of a local pattern that reference a ghost column (>= n_owned): the boundary rows of the
  * interior / boundary split of the multi-GPU SpMV -- interior rows are computed while the halo is in flight
  * (MatMult's VecScatter overlap in the reference's PETSc).  rows_out [n_owned], *n_out entries are valid.        */
-int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind,
+SNS_API int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind,
                            int32_t* rows_out, int32_t* n_out);
 
 /* eigenvalues of a small real upper-Hessenberg matrix (row-major n x n, n <= 32; entries below the first subdiagonal ignored):
  * the Ritz values of the short Arnoldi process that caps the smoother damping (amg_ritz_limit).                          */
-int sns_host_hessenberg_eigs(int n, const double* H, double* re_out, double* im_out);
+SNS_API int sns_host_hessenberg_eigs(int n, const double* H, double* re_out, double* im_out);
 
 #ifdef __cplusplus
 }

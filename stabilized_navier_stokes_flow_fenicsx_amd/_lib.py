@@ -94,6 +94,7 @@ _SIGNATURES = [
     ("sns_attach_team", C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int32, C.c_int, _P, _P, _P, _P, _P]),
     ("sns_peer_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(_P), C.c_char_p]),
     ("sns_peer_connect", C.c_int, [_P, C.c_char_p]),
+    ("sns_peer_disconnect", C.c_int, [_P]),
     ("sns_peer_destroy", C.c_int, [_P]),
     ("sns_peer_check_links", C.c_int, [_P, C.c_int]),
     ("sns_peer_selftest", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

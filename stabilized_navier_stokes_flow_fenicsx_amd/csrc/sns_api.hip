@@ -126,6 +126,7 @@ struct sns_ctx {
     int64_t ctr_host_syncs = 0, ctr_allreduce = 0, ctr_exchange = 0;
     int64_t last_ctr[3] = {0, 0, 0};                 // snapshot at the end of the last Krylov solve
     int bnd_dot_blocks = 0;
+    int dot_partials = 0;                            // partial sums the last fused SpMV+dot pass left in h->partial
     // multi-GPU, level 0: owned rows with at least one ghost column (the only rows that must wait for the halo)
     int32_t* bnd_rows = nullptr;
     uint8_t* bnd_flag = nullptr;
@@ -445,8 +446,11 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         s3.mode = 3;
         s3.gs = comm_ghost_src(c, c->plans[0]);
         pass(s3);
+        h->dot_partials = (rows + 31) / 32;              // (one per workgroup in this form of the pass)
         return SNS_OK;
     }
+    h->dot_partials = 4 * ((rows + 31) / 32);            // one per wave ...
+
     if (!dist || !h->bnd_flag || h->no_overlap || !h->opt.halo_overlap) {
         SNS_TRY(halo_exchange(h, xe));
         pass(Split());
@@ -457,7 +461,7 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
     s1.mode = 1;
     s2.mode = 2;
     s2.partial_off = gs;
-    if (MODE == SPMV_AX_DOT) h->bnd_dot_blocks = (h->n_bnd + 31) / 32;
+    if (MODE == SPMV_AX_DOT) { h->bnd_dot_blocks = (h->n_bnd + 31) / 32; h->dot_partials += 4 * h->bnd_dot_blocks; }   // ... of both launches
     if (c->nccl || (c->peer && !c->team) || h->team_overlap) {
         // (team transport with SNS_TEAM_OVERLAP=1: the same two-stream choreography -- interior pass on the side
         // stream, event joins, per-launch timing events on that stream -- over the emulated exchange, so that the
@@ -2367,7 +2371,8 @@ int dot(sns_ctx* h, const double* x, const double* y, double* out) {
 double* fused_first_sweep_target(sns_ctx* h, double* zdst) {
     if (h->opt.pc_type != SNS_PC_AMG || h->levels.size() < 2 || h->opt.amg_fine_cycle != 0 || !h->pc_ready) return nullptr;
     const Level& L = h->levels[0];
-    if (block_active(h, 0) || lp_format(h, L) == 0 || !L.dinv32 || L.n_owned <= 0) return nullptr;
+    if (lp_format(h, L) == 0 || !L.dinv32 || L.n_owned <= 0) return nullptr;
+    if (block_active(h, 0) && (!L.binv32 || L.n_blk <= 0)) return nullptr;      // (aggregate blocks: k_bfirst_bicg, see fused_vector_kernel)
     if (h->rep_level == 1) return nullptr;                       // level 0 is only the source of the replicated copy
     double* x = (h->n > h->n_owned && !fine_tails_unused(h)) ? h->levels[0].x : zdst;   // (as pc_apply chooses the cycle's vector)
     return cycle_start_buffer(h, 0, x);
@@ -2418,10 +2423,8 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
         auto first_half = [&](bool p_done) -> int {       // p, ph = M p, v = A ph, alpha
             if (!p_done) hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, p);
             SNS_TRY(pc_apply(h, p, ph));
-            const int32_t rows = h->n_owned;
-            const int gs = (rows + 31) / 32;
             SNS_TRY(op_apply_dot(h, ph, v, rhat));        // v = A ph with the fused partial sums of <rhat, v>
-            SNS_TRY(reduce_bicg<1>(h, 4 * (gs + h->bnd_dot_blocks), red, sc));     // one partial per wave; alpha
+            SNS_TRY(reduce_bicg<1>(h, h->dot_partials, red, sc));                  // alpha
             return SNS_OK;
         };
         SNS_TRY(first_half(false));
@@ -2430,8 +2433,21 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
         int best_it = 0;
         for (its = 1;; ++its) {
             if (double* z1 = fused_first_sweep_target(h, sh)) {
-                hipLaunchKernelGGL(k_bicg_s_first, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s, h->levels[0].dinv32,
-                                   h->levels[0].omega, z1);
+                const Level& L0 = h->levels[0];
+                if (block_active(h, 0)) {
+                    const int32_t ns = 8 * L0.n_blk;
+                    const unsigned gb = (unsigned)((ns + 63) / 64);
+                    if (L0.binv_fmt == 2)
+                        hipLaunchKernelGGL((k_bfirst_bicg<2, 1>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows, (const void*)L0.binv32,
+                                           L0.omega, z1, sc, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, v,
+                                           (double*)nullptr, r, (double*)nullptr, s);
+                    else
+                        hipLaunchKernelGGL((k_bfirst_bicg<1, 1>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows, (const void*)L0.binv32,
+                                           L0.omega, z1, sc, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, v,
+                                           (double*)nullptr, r, (double*)nullptr, s);
+                } else {
+                    hipLaunchKernelGGL(k_bicg_s_first, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s, L0.dinv32, L0.omega, z1);
+                }
                 h->first_sweep_done = true;
             } else {
                 hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
@@ -2447,8 +2463,22 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             const bool spec = its < o.ksp_max_it;
             if (spec) {
                 if (double* z1 = fused_first_sweep_target(h, ph)) {
-                    hipLaunchKernelGGL(k_bicg_xrp_first, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p,
-                                       h->levels[0].dinv32, h->levels[0].omega, z1);
+                    const Level& L0 = h->levels[0];
+                    if (block_active(h, 0)) {
+                        const int32_t ns = 8 * L0.n_blk;
+                        const unsigned gb = (unsigned)((ns + 63) / 64);
+                        if (L0.binv_fmt == 2)
+                            hipLaunchKernelGGL((k_bfirst_bicg<2, 2>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows,
+                                               (const void*)L0.binv32, L0.omega, z1, sc, (const double*)ph, (const double*)sh,
+                                               (const double*)t, (const double*)v, x, r, p, s);
+                        else
+                            hipLaunchKernelGGL((k_bfirst_bicg<1, 2>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows,
+                                               (const void*)L0.binv32, L0.omega, z1, sc, (const double*)ph, (const double*)sh,
+                                               (const double*)t, (const double*)v, x, r, p, s);
+                    } else {
+                        hipLaunchKernelGGL(k_bicg_xrp_first, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p,
+                                           L0.dinv32, L0.omega, z1);
+                    }
                     h->first_sweep_done = true;
                 } else {
                     hipLaunchKernelGGL(k_bicg_xrp, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p);
@@ -3217,6 +3247,7 @@ int sns_peer_create(int device, int rank, int nranks, int64_t window_bytes, void
     return SNS_OK;
 }
 int sns_peer_connect(void* peer, const char* ipc_handles) { return peer_connect(static_cast<Peer*>(peer), ipc_handles); }
+int sns_peer_disconnect(void* peer) { return peer_close_mappings(static_cast<Peer*>(peer)); }
 int sns_peer_destroy(void* peer) { return peer_destroy(static_cast<Peer*>(peer)); }
 int sns_peer_check_links(void* peer, int rounds) { return peer_check_links(static_cast<Peer*>(peer), rounds); }
 int sns_peer_selftest(int device, int nranks, int halo_nodes, int reps, double us_out[3]) {
@@ -3555,7 +3586,7 @@ int sns_bench_spmv(sns_handle h, const double* x, double* y, int reps, double* m
 //   which 0: fp64 y = Ax, default loads (0) vs non-temporal matrix stream (1, production)
 //   which 3: fp64 y = Ax, production (0: first 16 blocks up-front) vs the stepped loop of round 1 / early round 2 (1)
 //   which 1: low-precision Jacobi sweep, fp16 row-scaled (0) vs fp32 (1) (needs both copies: SNS_BOTH_LP=1)
-int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]) {
+SNS_API int sns_bench_variants(sns_handle h, int which, int rounds, int reps, double ms_out[2]) {   // (harness build only: not in sns.h)
     if (!h || !ms_out || rounds <= 0 || reps <= 0) return SNS_E_ARG;
     if (!h->has_matrix) { set_error("bench_variants before a matrix was assembled"); return SNS_E_STATE; }
     Level& L = h->levels[0];

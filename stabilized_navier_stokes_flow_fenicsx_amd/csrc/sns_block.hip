@@ -272,6 +272,53 @@ __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* 
 template __global__ void k_bfirst<1>(int32_t, const int32_t*, const void*, const double*, double, double*);
 template __global__ void k_bfirst<2>(int32_t, const int32_t*, const void*, const double*, double, double*);
 
+// The FINE level's first sweep (aggregate blocks: partitioned handles of the strong split, amg_block_fine_rows) inside the BiCGStab
+// vector kernel that produces the cycle's input -- what k_bicg_s_first / k_bicg_xrp_first are to the nodal blocks: one dependent
+// launch and one read of the input less per cycle.  The dofs are walked in the order of the aggregates (every owned node is in
+// exactly one), the vector updates are elementwise, so the order does not matter to them.  (z may be the buffer ph or sh was read
+// from -- every lane reads its own entry before it writes it; those three carry no __restrict__.)
+//   OP 1: s = r - alpha v;                                           z = w B^-1 s
+//   OP 2: x += alpha ph + omega sh;  r = s - omega t;  p = r + beta (p - omega v);      z = w B^-1 p
+template <int FMT, int OP>
+__global__ __launch_bounds__(256) void k_bfirst_bicg(int32_t n_slots, const int32_t* __restrict__ blk_rows,
+                                                     const void* __restrict__ binv, double omega_pc, double* z,
+                                                     const double* __restrict__ sc, const double* ph, const double* sh,
+                                                     const double* __restrict__ t,
+                                                     const double* __restrict__ v, double* __restrict__ x, double* __restrict__ r,
+                                                     double* __restrict__ p, double* __restrict__ s) {
+    __shared__ double sres[8 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t row = in ? blk_rows[slot] : -1;
+    const bool live = row >= 0;
+    BinvRow<FMT> Bv;
+    Bv.load(binv, slot >> 3, j, in);
+    double val = 0.0;
+    if (live) {
+        const int64_t i = 4 * (int64_t)row + c;
+        if (OP == 1) {
+            val = r[i] - sc[1] * v[i];
+            s[i] = val;
+        } else {
+            const double alpha = sc[1], omega = sc[2], beta = sc[3];
+            x[i] += alpha * ph[i] + omega * sh[i];
+            const double rn = s[i] - omega * t[i];
+            r[i] = rn;
+            val = rn + beta * (p[i] - omega * v[i]);
+            p[i] = val;
+        }
+    }
+    const double zz = block_apply(Bv, val, sres + 32 * (tid >> 5), j);
+    if (live) z[4 * (int64_t)row + c] = omega_pc * zz;
+}
+#define SNS_INST_BFB(F, O)                                                                                                  \
+    template __global__ void k_bfirst_bicg<F, O>(int32_t, const int32_t*, const void*, double, double*, const double*,         \
+                                                 const double*, const double*, const double*, const double*, double*, double*, \
+                                                 double*, double*);
+SNS_INST_BFB(1, 1) SNS_INST_BFB(1, 2) SNS_INST_BFB(2, 1) SNS_INST_BFB(2, 2)
+#undef SNS_INST_BFB
+
 // Restriction to a level that is smoothed with aggregate blocks, fused with that level's first sweep from the zero guess:
 //     bc[I] = sum_{i in I} free_i r[i]   (k_restrict's gather, same member order => same bits),     z = w_c B_c^-1 bc.
 // The coarse nodes are walked in the order of THEIR aggregates (blk_rows_c of the coarse level), so that the 32 lanes of a

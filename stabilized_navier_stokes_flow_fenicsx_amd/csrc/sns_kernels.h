@@ -135,6 +135,10 @@ __global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t*
                         const double* res1, double omega, const int32_t* agg, const uint8_t* free_mask, double* y, GhostSrc gs);
 template <int FMT>
 __global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const void* binv, const double* bvec, double omega, double* z);
+template <int FMT, int OP>
+__global__ void k_bfirst_bicg(int32_t n_slots, const int32_t* blk_rows, const void* binv, double omega_pc, double* z, const double* sc,
+                              const double* ph, const double* sh, const double* t, const double* v, double* x, double* r, double* p,
+                              double* s);
 template <int FMT>
 __global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                const uint8_t* free_mask, const double* r, double* bc, const void* binv_c, double omega_c, double* z_c);

@@ -1478,7 +1478,16 @@ __global__ __launch_bounds__(256) void k_spmv(int32_t n_rows, const int32_t* __r
         // 8 rows are done); the host reduces 4 * gridDim.x entries
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
-        if (lane == 0) partial[4 * ((int64_t)blockIdx.x + partial_off) + (tid >> 6)] = pr;
+        if (SPLIT == 3) {
+            // the latency-bound strong split: ONE partial per workgroup (a rank's 217 k rows leave 6.8 k instead of 27 k partials,
+            // which the single-workgroup final stage takes without the chunk kernel in front of it)
+            __shared__ double wsum[4];
+            if (lane == 0) wsum[tid >> 6] = pr;
+            __syncthreads();
+            if (tid == 0) partial[(int64_t)blockIdx.x + partial_off] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        } else if (lane == 0) {
+            partial[4 * ((int64_t)blockIdx.x + partial_off) + (tid >> 6)] = pr;
+        }
     }
 }
 

@@ -429,6 +429,8 @@ class PeerGroup:
             import torch.distributed as dist
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.dist_group)                          # nobody stores into a window that is about to go
+            self.lib.sns_peer_disconnect(self.ptr)                       # unmap the others' windows ...
+            dist.barrier(group=self.dist_group)                          # ... and free the own one only when nobody has it mapped
             self.lib.sns_peer_destroy(self.ptr)
             self.ptr = None
 

@@ -253,11 +253,14 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert d["n_gpus"] == 3 and d["config"]["halo_plans_consistent_ranks"] == 3 and d["config"]["owned_nodes_total"] == 343
 
 
-def test_bench_repeats_a_crashed_launch_once_without_the_two_stream_overlap():
+def test_bench_repeats_a_crashed_launch_once_without_the_two_stream_overlap(tmp_path):
     """A first attempt that fails fast is repeated ONCE with SNS_NO_OVERLAP=1 (halo exchange and operator pass on one
     stream) and the result line says so; a launch that works carries launch_fallback = null."""
     import json
-    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"], {"SNS_DRYRUN_CRASH_WITH_OVERLAP": "1"})
+    # (the first attempt's record goes to a directory of the test's own: a CPU test must not leave a file in the repo's
+    # gpurun_out/ that reads like a GPU-side crash record -- VERDICT r4)
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"],
+                              {"SNS_DRYRUN_CRASH_WITH_OVERLAP": "1", "SNS_BENCH_LOG_DIR": str(tmp_path)})
     assert rc == 0, err[-2000:]
     assert "one more attempt with SNS_NO_OVERLAP=1" in err
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -268,8 +271,8 @@ def test_bench_repeats_a_crashed_launch_once_without_the_two_stream_overlap():
     # stderr tail are on file
     assert d["degraded"] is True
     rec = d["launch_fallback"].split("record: ")[1].rstrip(")")
+    assert os.path.dirname(rec) == str(tmp_path)
     assert os.path.exists(rec) and "first attempt (overlapped halo) exited" in open(rec).read()
-    os.remove(rec)
     rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6"])
     d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
     assert rc == 0 and d["launch_fallback"] is None and d["degraded"] is False
@@ -301,6 +304,43 @@ def test_bench_weak_leg_deadline_keeps_the_headline_line():
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     rc, out, err = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
     assert rc == 2 and "WORLD_SIZE" in err and out.strip() == ""
+
+
+def test_bench_secondary_legs_share_one_budget():
+    """headline + peer leg + weak leg must fit the driver's clock (600 s) whatever the legs do.  The legs take
+    their deadlines from ONE --budget (an equal share of what is left, at most their own cap; too little left = skipped), so the
+    one line is out and every rank has exited 0 inside it.  Here with real ranks (dry run, both legs never come back): the
+    peer leg's share of a 24-s budget expires, rank 0 prints THE line, both ranks exit 0 -- well inside the budget; and with a
+    budget that leaves no room the legs are skipped and say so."""
+    import json
+    import time
+    env = {"SNS_DRYRUN_PEER_STALL": "1", "SNS_DRYRUN_WEAK_STALL": "1", "SNS_WATCHDOG_S": "600", "SNS_BENCH_MIN_LEG_S": "2",
+           "SNS_BENCH_RESERVE_S": "4"}
+    t0 = time.time()
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6", "--budget", "24", "--peer-timeout", "300",
+                               "--weak-timeout", "300"], env, timeout=200)
+    took = time.time() - t0
+    assert rc == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert "timeout" in d["peer_transport"]["error"] and "peer-transport leg exceeded" in err
+    assert took < 24 + 25, took                     # (the budget + the launcher's own start-up and teardown)
+    # no room at all: both legs are skipped, the line still comes
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--cells", "24,6,6", "--budget", "1"], env, timeout=200)
+    assert rc == 0, err[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert "skipped" in d["peer_transport"] and "skipped" in d["weak_scaling"]
+    # the arithmetic itself: equal shares of what is left, capped, never below the minimum
+    import bench
+    now = bench.T_START + 100.0
+    assert bench.leg_seconds(540.0, 300.0, 2, now=now) == (540.0 - 100.0 - bench.LEG_RESERVE_S) / 2
+    assert bench.leg_seconds(540.0, 150.0, 2, now=now) == 150.0
+    assert bench.leg_seconds(540.0, 300.0, 1, now=bench.T_START + 540.0 - bench.LEG_RESERVE_S - 5.0) == 0.0
+    # headline 200 s + peer leg at its share + weak leg at its share stay inside 540 s
+    t_peer = bench.leg_seconds(540.0, 300.0, 2, now=bench.T_START + 200.0)
+    t_weak = bench.leg_seconds(540.0, 300.0, 1, now=bench.T_START + 200.0 + t_peer)
+    assert 200.0 + t_peer + t_weak <= 540.0 - bench.LEG_RESERVE_S + 1e-9
 
 
 def test_bench_shared_gpu_rehearsal_needs_the_peer_transport():

@@ -604,6 +604,57 @@ def test_two_stream_halo_overlap_matches_exchange_then_full_pass(gpu, nranks, mo
         assert rel(Ua[:no], Ub[:no]) < 1e-10 and rel(wa[:no], wb[:no]) < 1e-10
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
+    """Round 5: the window form of the partitioned cycle (halo_windows: one put launch per exchange, the level passes read their
+    ghost entries from the receive window) with a PARTITIONED, aggregate-block-smoothed level 1 above the replicated tail
+    (amg_replicate_rows lowered so that the 96 x 24 x 24 duct has one): amg_exact_sweeps = 1 runs the single-GPU schedule there
+    (1 + 3 exact global sweeps, the correction inside the first post-sweep, its coarse solution read straight from the
+    replicated level), = 0 round 4's 4 + 4 rank-local sweeps; halo_windows = 0 is round 4's exchange.  All three reach the serial
+    fields; the exact cycle needs no more iterations than the rank-local one."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
+    from stabilized_navier_stokes_flow_fenicsx_amd.solver import Team
+    from stabilized_navier_stokes_flow_fenicsx_amd import bcs as B, mesh as M
+    cells, Re = (96, 24, 24), 40.0
+    m = M.duct_mesh(cells, 4.0)
+    Ps = gpu(m, B.duct_bcs(m).flatten(), reynolds=Re)
+    Us, rs = Ps.stokes_solve()
+    ws, ns = Ps.newton_solve(Us.clone())
+    Us, ws = Us.cpu().numpy(), ws.cpu().numpy()
+    Ps.close()
+    res = {}
+    for name, kw in (("exact", dict(halo_windows=1, amg_exact_sweeps=1)), ("local", dict(halo_windows=1, amg_exact_sweeps=0)),
+                     ("round4", dict(halo_windows=0, amg_exact_sweeps=0))):
+        team = Team(nranks)
+
+        def work(rank, team):
+            P = gpu.from_part(PT.duct_slab_part(cells, 4.0, rank, nranks), group=team, reynolds=Re, amg_replicate_rows=2000, **kw)
+            U, r = P.stokes_solve()
+            c = P.counters()
+            w, n = P.newton_solve(U.clone())
+            out = (P.part, U.cpu().numpy(), r, w.cpu().numpy(), n, [(x["kind"], x["pre"], x["post"]) for x in P.cycle()],
+                   [hh["rows"] for hh in P.hierarchy()], c)
+            P.close()
+            return out
+
+        outs = team.run(work)
+        team.close()
+        Ug, wg = np.zeros(m.num_dofs), np.zeros(m.num_dofs)
+        for part, U, r, w, n, cyc, rows, c in outs:
+            gd = (4 * part.l2g[:part.n_owned, None] + np.arange(4)[None]).ravel()
+            Ug[gd], wg[gd] = U[:4 * part.n_owned], w[:4 * part.n_owned]
+            assert r.reason > 0 and n.reason == ns.reason and (r.its, n.ksp_its) == (outs[0][2].its, outs[0][4].ksp_its)
+        print(f"  {nranks} ranks, {name}: stokes {outs[0][2].its} its, newton ksp {outs[0][4].ksp_its}, cycle {outs[0][5]}, rows {outs[0][6]}, "
+              f"{outs[0][7]['exchanges']} exchanges in the Stokes solve (serial: stokes {rs.its}, newton ksp {ns.ksp_its})")
+        assert rel(Ug, Us) < 1e-6 and rel(wg, ws) < 1e-8
+        res[name] = outs[0]
+    cyc_e, cyc_l = res["exact"][5], res["local"][5]
+    assert cyc_e[1][0] == 1 and (cyc_e[1][1], cyc_e[1][2]) == (1, 3), cyc_e           # partitioned level 1: aggregate blocks, 1 + 3
+    assert (cyc_l[1][1], cyc_l[1][2]) == (4, 4) and res["round4"][5] == cyc_l, cyc_l
+    assert res["exact"][4].ksp_its <= res["local"][4].ksp_its + 2
+    assert res["local"][2].its == res["round4"][2].its and res["local"][4].ksp_its == res["round4"][4].ksp_its
+
+
 @pytest.mark.parametrize("opts", [dict(amg_post_exchange=0, amg_replicate_rows=0),
                                   dict(amg_post_exchange=1, amg_replicate_rows=0, amg_sweep_exchange_rows=300),
                                   dict(amg_post_exchange=0, amg_replicate_rows=1 << 20, amg_coarse_size=24),

@@ -71,9 +71,12 @@ def _run_ranks(kind, world, tmp_path, env_extra=None, deadline=420.0):
     return res
 
 
-@pytest.mark.parametrize("kind,world", [("duct", 3), ("duct-rep-dense", 3), ("cavity", 4)])
-def test_partitioned_solve_between_processes_over_peer_windows(kind, world, tmp_path):
-    res = _run_ranks(kind, world, tmp_path)
+@pytest.mark.parametrize("kind,world,opts", [("duct", 3, None), ("duct-rep-dense", 3, None), ("cavity", 4, None),
+                                             # round 4's form of the exchange (put + wait / unpack into the ghost tail, interior rows on
+                                             # a second stream meanwhile): what RCCL-shaped code paths and halo_windows = 0 run
+                                             ("cavity", 4, {"halo_windows": 0, "amg_exact_sweeps": 0})])
+def test_partitioned_solve_between_processes_over_peer_windows(kind, world, opts, tmp_path):
+    res = _run_ranks(kind, world, tmp_path, env_extra={"SNS_TEST_OPTS": json.dumps(opts)} if opts else None)
     for r in res:
         assert r["ok"], r
     print("  " + kind + ": " + "; ".join(f"rank {r['rank']}: {r['n_owned']} nodes, nbrs {r['neighbors']}, stokes {r['stokes_its']} its, "

@@ -102,6 +102,12 @@ def test_header_symbols_match_library(built_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} not exported"
+    # ... and NOTHING else (-fvisibility=hidden + the version script csrc/sns_exports.map -- no C++ internals, no
+    # kernel handles in the dynamic symbol table): nm -D of the library == the header's declarations
+    import subprocess
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode().split("\n")
+    exported = {ln.split()[-1] for ln in nm if ln.strip() and ln.split()[-2] in "TtWw"}
+    assert exported == declared, (sorted(exported - declared)[:5], sorted(declared - exported)[:5])
     o = _lib.default_options()
     assert o.ksp_rtol == 1e-8 and o.snes_max_it == 30 and o.snes_rtol == 1e-8     # reference's settings :281-283
 
