@@ -40,10 +40,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=str, default="5", choices=["3", "4", "4u", "5"],
+    ap.add_argument("--config", type=str, default="5", choices=["3", "4", "4b", "4u", "5"],
                     help="BASELINE config: 5 = 10.1 M-tet duct Re 200 (headline), 3 = 55^3 cavity Re 100, "
                          "4 = 240x60x60 channel Re 50 with the inlet profiles of the reference's Plus image "
-                         "(--inlet analytic: the two-stream substitute of round 2), 4u = Delaunay channel (~5 M tets)")
+                         "(--inlet analytic: the two-stream substitute of round 2), 4b = the same image on the BODY-FITTED nozzle "
+                         "channel of nozzle_mesh.py (--cells = 1000 x channel_mesh_size, default 20 -> lc 0.020, 4.66 M tets), "
+                         "4u = Delaunay channel (~5 M tets)")
     ap.add_argument("--inlet", type=str, default="image", choices=["image", "analytic"],
                     help="config 4: inlet data from tests/golden/inlet_PlusF_final.png (default) or analytic")
     ap.add_argument("--cells", type=str, default=None)
@@ -366,6 +368,14 @@ def host_problem(cfg, cells, length, inlet="image"):
     if cfg == "3":                         # LidDrivenNavierStokesFlow.py extended to the unit cube
         mesh = M.cavity_mesh(cells[0])
         return mesh, B.cavity_bcs(mesh).flatten(), f"lid-driven unit cube, {cells[0]}^3 cells"
+    if cfg == "4b":                        # NavierStokesChannelFlow.py on the geometry image2gmsh3D.py:164-486 builds: nozzle_mesh.py
+        from stabilized_navier_stokes_flow_fenicsx_amd import nozzle_mesh as NM
+        img = os.path.join(ROOT, "tests", "golden", "inlet_PlusF_final.png")
+        lc = cells[0] / 1000.0
+        mesh, bcs, _ = NM.channel_from_image_bodyfitted(img, 0.5, lc)
+        return mesh, bcs, (f"channel 4x1x1 minus the nozzle wall of the reference's Plus image extruded over x in [0, 0.5] (body-fitted, "
+                           f"channel_mesh_size {lc:g}: {mesh.meta['planes']} node planes x {mesh.meta['cross_section_triangles']} cross-section "
+                           "triangles), inlet profiles from the image, flowrate ratio 0.5")
     if cfg == "4u":                        # the reference's production meshes are gmsh Delaunay (image2gmsh3D.py:445-486)
         mesh = M.delaunay_channel_mesh(cells[0], lattice="bcc")
         return (mesh, B.channel_bcs(mesh, *B.two_stream_profiles(0.5)).flatten(),
@@ -726,7 +736,7 @@ def main():
         return 2
     WATCHDOG = Watchdog(rank)
     cfg = args.config
-    default_cells = {"5": "300,75,75", "4": "240,60,60", "4u": "47", "3": "55,55,55"}[cfg]
+    default_cells = {"5": "300,75,75", "4": "240,60,60", "4b": "20", "4u": "47", "3": "55,55,55"}[cfg]
     cells = tuple(int(c) for c in (args.cells or default_cells).split(","))
     length = args.length
     if args.dry_run:
@@ -753,7 +763,7 @@ def main():
             from stabilized_navier_stokes_flow_fenicsx_amd.solver import PeerGroup
             peers = PeerGroup(device=f"cuda:{local_rank}")
 
-    Re = args.re if args.re is not None else {"5": 200.0, "4": 50.0, "4u": 50.0, "3": 100.0}[cfg]
+    Re = args.re if args.re is not None else {"5": 200.0, "4": 50.0, "4b": 50.0, "4u": 50.0, "3": 100.0}[cfg]
     opts = dict(reynolds=Re, ksp_type=args.ksp, pc_type="amg", snes_max_it=1)
     for kv in args.opt:
         k, v = kv.split("=", 1)

@@ -259,6 +259,13 @@ SNS_API int sns_destroy(sns_handle h);
 SNS_API int sns_set_stream(sns_handle h, void* hip_stream);
 SNS_API int sns_set_options(sns_handle h, const sns_options* opt);
 SNS_API int sns_get_options(sns_handle h, sns_options* opt);
+/* DIAGNOSTIC (round 5): perturb the 3-D NS form of define_navier_stokes_form (:220-251) -- the study of what the reference-held
+ * constants (DFG_2D_Validation.py:202-203) can tell apart, tests/test_gpu_2d.py.  c_inverse: C_I of the G-metric tau (:237; 36;
+ * 0 drops the 36 nu^2 G:G term), lsic_scale: factor on nu_L (:249; 1; 0 = no LSIC term), pspg_sign: sign of (tau res_M, grad q)
+ * (:247; +1), one_point_quadrature != 0: the 1-point centroid rule instead of the 4-point rule of dx(degree 2) (:222).  The values
+ * in brackets restore the reference's form.  A perturbed form is assembled by the staged element kernel (Jacobian and residual,
+ * exact Gateaux derivative of the perturbed form); the matrix must be re-assembled afterwards.                                 */
+SNS_API int sns_set_form_variant(sns_handle h, double c_inverse, double lsic_scale, double pspg_sign, int one_point_quadrature);
 
 /* sizes: n_owned = rows this rank owns, n_local = owned + ghost nodes */
 SNS_API int sns_get_sizes(sns_handle h, int32_t* n_local_nodes, int32_t* n_owned_nodes,

@@ -61,9 +61,16 @@ def _safe_norm(u):
     return torch.where(pos, torch.sqrt(torch.where(pos, uu, torch.ones_like(uu))), torch.zeros_like(uu))
 
 
+# Perturbations of the form for the study "what do the reference-held constants catch" (oracle/experiments/r5_pin_variants_2d.py;
+# the defaults ARE the reference's form): factor on tau_LSIC, sign of the PSPG term, the coefficient 4 of tau_SUNG3 = h^2 / (4 nu),
+# the 1-point centroid rule in place of the 3-point rule of dx(degree 2).
+VARIANT = dict(lsic=1.0, pspg=1.0, sung3=4.0, one_point=False)
+
+
 def ugn_residual_one(X, w, nu):
     """9-vector a(w; v, q) for one triangle.  X (3,2), w (9,) = [ux,uy,p]*3 (torch fp64)."""
     detJ, gphi, h = _geometry(X)
+    V = VARIANT
     W = w.reshape(3, 3)
     U, P = W[:, :2], W[:, 2]
     grad_u = torch.einsum("ai,aj->ij", U, gphi)                          # grad(u)[i,j]
@@ -74,18 +81,18 @@ def ugn_residual_one(X, w, nu):
     r = 2
     total = torch.zeros(9, dtype=_T)
     for q in range(3):
-        phi = _phi(torch.as_tensor(QPTS[q], dtype=_T))
+        phi = _phi(torch.as_tensor([1 / 3, 1 / 3] if V["one_point"] else QPTS[q], dtype=_T))
         u = torch.einsum("a,ai->i", phi, U)
         p = torch.dot(phi, P)
         u_norm = _safe_norm(u)                                           # sqrt(dot(u,u))
         safe_un = torch.where(u_norm > 1e-8, u_norm, torch.ones_like(u_norm))
         tau_SUNG1 = h / (2 * safe_un)
         inv_tau_SUNG1 = torch.where(u_norm <= 1e-8, torch.zeros_like(u_norm), 1 / (tau_SUNG1 ** r))
-        tau_SUNG3 = h * h / (4 * nu)
+        tau_SUNG3 = h * h / (V["sung3"] * nu)
         tau_SUPG = (inv_tau_SUNG1 + 1 / (tau_SUNG3 ** r)) ** (-1 / r)
         Re_UGN = u_norm * h / (2 * nu)
         z = torch.where(Re_UGN <= 3, Re_UGN / 3, torch.ones_like(Re_UGN))
-        tau_LSIC = h / 2 * u_norm * z
+        tau_LSIC = V["lsic"] * h / 2 * u_norm * z
         conv = u @ nabla_grad_u                                          # dot(u, nabla_grad(u))
         # P1 on an affine cell: div(sym(grad(u))) = 0
         res = conv + grad_p
@@ -110,7 +117,7 @@ def ugn_residual_one(X, w, nu):
                 t = t - p * div_v                                        # pressure
                 t = t + qt * div_u                                       # incompressibility
                 t = t + tau_SUPG * torch.dot(u @ grad_v.T, res)          # SUPG: dot(u, nabla_grad(v))
-                t = t + tau_SUPG * torch.dot(grad_q, res)                # PSPG
+                t = t + V["pspg"] * tau_SUPG * torch.dot(grad_q, res)    # PSPG
                 t = t + tau_LSIC * div_v * div_u                         # LSIC
                 vals.append(wq * t)
         total = total + torch.stack(vals)

@@ -85,6 +85,7 @@ _SIGNATURES = [
     ("sns_set_stream", C.c_int, [_H, _P]),
     ("sns_set_options", C.c_int, [_H, C.POINTER(SnsOptions)]),
     ("sns_get_options", C.c_int, [_H, C.POINTER(SnsOptions)]),
+    ("sns_set_form_variant", C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_int]),
     ("sns_get_sizes", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int64)]),
     ("sns_comm_unique_id", C.c_int, [C.c_char_p]),

@@ -96,6 +96,7 @@ struct sns_ctx {
     std::vector<double*> pong;                   // per level smoother ping-pong buffer
     int* d_piv = nullptr;
     int* d_sing = nullptr;
+    FormVariant fv;                              // sns_set_form_variant (diagnostic; default = the reference's form)
     bool has_matrix = false, pc_ready = false;
     int pc_setups = 0;
     // hipGraph of the launch-bound coarse part of the V-cycle (levels >= graph_level; serial runs only)
@@ -163,6 +164,7 @@ struct sns_ctx {
     std::vector<std::vector<int32_t>> ghost_gid;  // per level: (owner rank, owner-local id) of each ghost node
     std::vector<std::vector<int32_t>> ghost_own;
     std::unique_ptr<HostPattern> pattern;      // kept until the (lazy) hierarchy build
+    std::vector<double> host_pts;              // ... with the node coordinates (3 per node): the aggregation's strength filter on anisotropic meshes
     // optional per-launch timing of the fine-level SpMV family
     bool time_kernels = false;
     std::vector<std::array<hipEvent_t, 2>> ev_pool;
@@ -908,6 +910,8 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
     const bool dist = c && c->active() && c->nranks > 1;
     HostPattern cur = fine;
     int32_t n_owned = h->n_owned;
+    std::vector<double> cur_pts = h->dim == 3 ? std::move(h->host_pts) : std::vector<double>();   // coordinates of `cur`'s nodes (coarse: centroids)
+    h->host_pts = std::vector<double>();
     {
         double ng[1] = {(double)h->n_owned};
         SNS_TRY(global_sum(h, ng, 1));
@@ -938,7 +942,8 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
         if (!dist && l >= 1 && n_owned <= coarsest_rows(o)) break;       // serial: this level is solved directly
         std::vector<int32_t> agg;
         int32_t nc_owned = 0;
-        aggregate_nodes(cur, n_owned, std::min(255, std::max(2, o.amg_agg_size)), agg, nc_owned);
+        aggregate_nodes(cur, n_owned, std::min(255, std::max(2, o.amg_agg_size)), agg, nc_owned,
+                        cur_pts.size() == (size_t)3 * cur.n ? cur_pts.data() : nullptr);
         double prog[2] = {(double)n_owned, (double)nc_owned};
         SNS_TRY(global_sum(h, prog, 2));
         if (prog[1] >= prog[0] || prog[1] == 0.0) break;      // no progress anywhere
@@ -1029,6 +1034,20 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
             if (nc_owned > 0)
                 hipLaunchKernelGGL(k_empty_coarse, dim3((unsigned)((4 * (int64_t)nc_owned + 255) / 256)), dim3(256), 0,
                                    h->stream, nc_owned, L.m_ptr, L.m_idx, L.free_mask, h->empty_c[0]);
+        }
+        if (cur_pts.size() == (size_t)3 * cur.n) {
+            std::vector<double> cp((size_t)3 * nc_total, 0.0), cnt((size_t)nc_total, 0.0);
+            for (int32_t i = 0; i < cur.n; ++i) {
+                const int32_t I = A.agg[(size_t)i];
+                if (I < 0) continue;
+                for (int c3 = 0; c3 < 3; ++c3) cp[3 * (size_t)I + c3] += cur_pts[3 * (size_t)i + c3];
+                cnt[(size_t)I] += 1.0;
+            }
+            for (int32_t I = 0; I < nc_total; ++I)
+                if (cnt[(size_t)I] > 0.0) for (int c3 = 0; c3 < 3; ++c3) cp[3 * (size_t)I + c3] /= cnt[(size_t)I];
+            cur_pts = std::move(cp);
+        } else {
+            cur_pts.clear();
         }
         cur = std::move(A.coarse);
         n_owned = nc_owned;
@@ -1146,7 +1165,9 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
     const int grid = (int)((h->E + EL_TETS_PER_BLOCK - 1) / EL_TETS_PER_BLOCK);
     const double nu = 1.0 / h->opt.reynolds;
     bool fast_residual = false;
-    const bool try_fused = want_matrix && h->opt.assembly_fused && form == SNS_FORM_NS && h->E > 0;
+    // (a perturbed form -- sns_set_form_variant -- exists in the staged element kernel only: Jacobian AND residual go through it)
+    const bool variant = !h->fv.is_default();
+    const bool try_fused = want_matrix && h->opt.assembly_fused && form == SNS_FORM_NS && h->E > 0 && !variant;
     if (((!want_matrix && F) || try_fused) && form == SNS_FORM_NS && h->E > 0) {
         // residual only: if the state satisfies the Dirichlet data there is no lifting term (:65) and the
         // one-lane-per-tet kernel applies; otherwise the general fused kernel computes the lifted blocks
@@ -1157,7 +1178,7 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
         reduce_local(h, gv, 1, h->d_scal + 60);
         double nviol = 1.0;
         SNS_TRY(fetch(h, h->d_scal + 60, 1, &nviol));
-        fast_residual = (nviol == 0.0);
+        fast_residual = (nviol == 0.0) && !variant;
     }
     Level& L = h->levels[0];
     if (form == SNS_FORM_STOKES && !w && want_matrix && h->opt.assembly_fused && h->E > 0) {
@@ -1222,13 +1243,13 @@ int assemble(sns_ctx* h, int form, const double* w, double* F, bool want_matrix)
     } else if (grid > 0) {
         if (form == SNS_FORM_STOKES)
             hipLaunchKernelGGL((k_element<SNS_FORM_STOKES, false>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
-                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe, h->fv);
         else if (!h->opt.corrected_convection)
             hipLaunchKernelGGL((k_element<SNS_FORM_NS, false>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
-                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe, h->fv);
         else
             hipLaunchKernelGGL((k_element<SNS_FORM_NS, true>), dim3(grid), dim3(256), 0, h->stream, h->E, h->tets,
-                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe);
+                               h->pts, w, h->bc_mask, h->bc_val, nu, want_matrix ? 1 : 0, h->Ke, Fe, h->fv);
     }
     if (want_matrix) {
         const int64_t nth = L.nnzb * 8;
@@ -3015,6 +3036,7 @@ static int create_common(int dim, sns_handle* out, int32_t n_nodes, int64_t n_te
     h->graph_disabled = std::getenv("SNS_NO_GRAPH") != nullptr;
     h->r3_estimates = std::getenv("SNS_R3_SPECTRAL_ESTIMATE") != nullptr;
     h->pattern.reset(new HostPattern(std::move(P)));
+    h->host_pts.assign(points, points + (size_t)3 * n_nodes);
     *out = h.release();
     return SNS_OK;
 }
@@ -3117,6 +3139,19 @@ int sns_set_options(sns_handle h, const sns_options* o) {
     if (pc_changed || damping_changed) h->pc_ready = false;
     if (damping_changed || pc_changed)
         for (auto& L : h->levels) { L.lambda_max = 0.0; L.omega_checked = 0.0; L.ritz_limit = 0.0; }   // re-estimate and re-verify
+    return SNS_OK;
+}
+int sns_set_form_variant(sns_handle h, double c_inverse, double lsic_scale, double pspg_sign, int one_point_quadrature) {
+    if (!h) return SNS_E_ARG;
+    if (h->dim != 3) { set_error("sns_set_form_variant: 3-D handles only"); return SNS_E_ARG; }
+    FormVariant fv;
+    fv.ci = c_inverse;
+    fv.lsic = lsic_scale;
+    fv.pspg = pspg_sign;
+    if (one_point_quadrature) fv.qa = fv.qb = 0.25;
+    h->fv = fv;
+    h->has_matrix = false;
+    h->pc_ready = false;
     return SNS_OK;
 }
 int sns_get_options(sns_handle h, sns_options* o) {

@@ -124,17 +124,61 @@ void build_pattern(int32_t n, int64_t E, const int32_t* tets, HostPattern& P, Ho
 // neighbour joins the aggregate of its first aggregated neighbour.  Sequential
 // and therefore deterministic; O(nnzb).  Rows >= fine.n_owned ... are handled by
 // the caller through `owned` (nodes outside are never aggregated).
+// Is the node cloud of a level anisotropic -- cells stretched in one direction, like the extruded nozzle channel whose planes lie
+// 2 lc apart over a cross-section of size lc / 2?  Measure: the median over the nodes of (longest / shortest edge)^2.  A Kuhn
+// box gives 3 (edge, face and body diagonals), body-centred and Delaunay meshes less, an extrusion with aspect ratio a about
+// a^2 + 1.  Above ANISO_ON the aggregation below keeps to the STRONG connections (round 5).
+constexpr double ANISO_ON = 6.0, ANISO_KEEP = 4.0;
+bool cloud_is_anisotropic(const HostPattern& F, int32_t n_active, const double* pts) {
+    if (!pts || n_active < 64) return false;
+    std::vector<double> ratio;
+    const int32_t step = std::max(1, n_active / 20000);                    // a sample of the nodes is enough
+    for (int32_t i = 0; i < n_active; i += step) {
+        double lo = 1e300, hi = 0.0;
+        for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+            const int32_t j = F.colind[k];
+            if (j == i) continue;
+            double d2 = 0.0;
+            for (int c = 0; c < 3; ++c) { const double d = pts[3 * (size_t)j + c] - pts[3 * (size_t)i + c]; d2 += d * d; }
+            lo = std::min(lo, d2);
+            hi = std::max(hi, d2);
+        }
+        if (hi > 0.0 && lo > 0.0) ratio.push_back(hi / lo);
+    }
+    if (ratio.size() < 16) return false;
+    std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+    return ratio[ratio.size() / 2] > ANISO_ON;
+}
+
+// Size-limited greedy aggregation.  With `pts` (3 coordinates per node of the level) on an ANISOTROPIC cloud a node only takes
+// (or joins) neighbours within 2x its shortest edge -- the strong couplings of a diffusion-dominated operator scale with
+// 1 / length^2, the block-Jacobi smoother handles exactly those, and aggregating along them alone is the semi-coarsening such
+// meshes need; on every other cloud (all of rounds 1-4's meshes) the filter is off and the aggregates are those of round 1.
 void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
-                            int32_t& nc) {
+                            int32_t& nc, const double* pts) {
     agg.assign((size_t)F.n, -1);
     nc = 0;
+    const bool strong_only = cloud_is_anisotropic(F, n_active, pts);
+    auto dist2 = [&](int32_t i, int32_t j) {
+        double d2 = 0.0;
+        for (int c = 0; c < 3; ++c) { const double d = pts[3 * (size_t)j + c] - pts[3 * (size_t)i + c]; d2 += d * d; }
+        return d2;
+    };
     for (int32_t i = 0; i < n_active; ++i) {
         if (agg[i] >= 0) continue;
+        double lim = 1e300;
+        if (strong_only) {
+            double lo = 1e300;
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k)
+                if (F.colind[k] != i) lo = std::min(lo, dist2(i, F.colind[k]));
+            lim = ANISO_KEEP * lo * (1.0 + 1e-9);
+        }
         int taken = 0;
         int32_t first_agg_nb = -1;
         for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
             int32_t j = F.colind[k];
             if (j == i || j >= n_active) continue;
+            if (strong_only && dist2(i, j) > lim) continue;
             if (agg[j] < 0) {
                 if (taken < max_agg - 1) { agg[j] = nc; ++taken; }
             } else if (first_agg_nb < 0) first_agg_nb = agg[j];

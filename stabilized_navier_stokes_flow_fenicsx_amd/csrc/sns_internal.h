@@ -108,7 +108,8 @@ struct Level {
     double ritz_limit = 0.0;             // stability limit of the damping from the Ritz values of S A (amg_ritz_limit; 0 = not estimated)
 };
 
-void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc);
+void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc,
+                     const double* pts = nullptr);
 void set_error(const std::string& s);
 
 }  // namespace sns

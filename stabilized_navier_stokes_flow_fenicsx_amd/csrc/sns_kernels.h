@@ -18,10 +18,20 @@ constexpr int EL_TETS_PER_BLOCK = 16;   // tets per 256-thread workgroup of k_el
 
 enum SpmvMode { SPMV_AX = 0, SPMV_B_MINUS_AX = 1, SPMV_JACOBI = 2, SPMV_AX_DOT = 3 };
 
+// Perturbations of the 3-D NS form for the study "what do the reference-held constants tell apart" (sns_set_form_variant; the
+// staged element kernel only): C_I of the G-metric tau (:237, 36), a factor on the LSIC viscosity nu_L (:249, 1), the sign of the
+// PSPG term (tau res_M, grad q) (:247, +1) and the quadrature points (a, b) of the 4-point rule (:222; a = b = 1/4 collapses
+// it to the 1-point centroid rule of the same total weight).  The defaults ARE the reference's form.
+struct FormVariant {
+    double ci = 36.0, lsic = 1.0, pspg = 1.0;
+    double qa = 0.1381966011250105, qb = 0.5854101966249685;
+    bool is_default() const { return ci == 36.0 && lsic == 1.0 && pspg == 1.0 && qa == 0.1381966011250105 && qb == 0.5854101966249685; }
+};
+
 template <int FORM, bool corrected>
 __global__ void k_element(int64_t n_tets, const int32_t* tets, const double* pts, const double* w,
                           const uint8_t* bc_mask, const double* bc_val, double nu, int store_K, double* Ke,
-                          double* Fe);
+                          double* Fe, FormVariant fv);
 template <int FORM, bool corrected>
 __global__ void k_fused_offdiag(int64_t n_od, const int32_t* od_order, const int64_t* c_ptr, const int32_t* c_idx, const int32_t* slot_row,
                                 const int32_t* colind, const int32_t* tets, const double* pts, const double* w,

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
                                                     const uint8_t* __restrict__ bc_mask,
                                                     const double* __restrict__ bc_val, double nu,
                                                     int store_K, double* __restrict__ Ke,
-                                                    double* __restrict__ Fe) {
+                                                    double* __restrict__ Fe, FormVariant fv) {
     // staging data and the output transpose tile share LDS (the tile is written after a barrier
     // that retires every read of the staging data): 34.8 KB per workgroup -> 4 workgroups per CU
     constexpr size_t SH_BYTES = sizeof(TetLds) * EL_TETS, TILE_BYTES = sizeof(double) * EL_TPB * 17;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
             for (int i = 0; i < 3; ++i) u[i] = 0.0;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
-                const double ph = phi_q(q, aa);
+                const double ph = (q == aa) ? fv.qb : fv.qa;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) u[i] += ph * W[4 * aa + i];
                 p += ph * W[4 * aa + 3];
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
 #pragma unroll
             for (int j = 0; j < 3; ++j)                       // res_M :241  (reference: dot(u, grad(u)) = (grad u)^T u)
                 r[j] = (corrected ? conv[j] : (gu[0][j] * u[0] + gu[1][j] * u[1] + gu[2][j] * u[2])) + gp[j];
-            const double tau = 1.0 / sqrt(uGu + 36.0 * nu * nu * GG);                     // :237-238
-            const double nuL = 1.0 / (trG * tau);                                        // :249
+            const double tau = 1.0 / sqrt(uGu + fv.ci * nu * nu * GG);                    // :237-238 (C_I = 36)
+            const double nuL = fv.lsic / (trG * tau);                                    // :249
             double* Q = S.q[q];
             Q[0] = u[0]; Q[1] = u[1]; Q[2] = u[2]; Q[3] = p; Q[4] = tau; Q[5] = nuL;
             Q[6] = Gu[0]; Q[7] = Gu[1]; Q[8] = Gu[2];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double* Q = S.q[q];
-                const double pa = phi_q(q, a), pb = phi_q(q, b);
+                const double pa = (q == a) ? fv.qb : fv.qa, pb = (q == b) ? fv.qb : fv.qa;
                 const double u[3] = {Q[0], Q[1], Q[2]};
                 const double tau = Q[4], nuL = Q[5];
                 const double Gu[3] = {Q[6], Q[7], Q[8]};
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const double dtau = -t3 * pb * Gu[j];                         // d tau / d u_(b,j)
-                    const double dnuL = (tau / trG) * pb * Gu[j];                 // d nu_L
+                    const double dnuL = fv.lsic * (tau / trG) * pb * Gu[j];       // d nu_L
                     cg[j] = dnuL * divu + nuL * gb[j];
                     if (!corrected) {
                         // d(r.g_a) = u_j g_a.g_b + phi_b ((grad u) g_a)_j
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
                             acc[4 * i + j] += pa * pb * gum[3 * i + j] + u[i] * cu[j] + ga[i] * cg[j];
                         acc[5 * i] += A1;
                         acc[4 * i + 3] += -pb * ga[i] + tau * u[i] * gab;        // J[(a,i),(b,p)]
-                        acc[12 + i] += pa * gb[i] + cu[i];                       // J[(a,p),(b,j)]
+                        acc[12 + i] += pa * gb[i] + fv.pspg * cu[i];             // J[(a,p),(b,j)]
                     }
-                    acc[15] += tau * gab;
+                    acc[15] += fv.pspg * tau * gab;
                 } else {
                     // corrected variant: res_M = (u.grad)u + grad p ; SUPG test = (u.grad)v + grad q
                     //   R[(a,i)] += tau (u.g_a) r_i ; R[(a,p)] += tau (r.g_a)
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
                         acc[5 * i] += A1;
                         acc[4 * i + 3] += -pb * ga[i] + tau * uga * gb[i];       // d r_i / d p_b = g_b[i]
                         // continuity row: phi_a g_b[j] + d(tau r.g_a)
-                        acc[12 + i] += pa * gb[i] + cu[i] * sa + tau * (ugb * ga[i] + pb * guga_a[i]);
+                        acc[12 + i] += pa * gb[i] + fv.pspg * (cu[i] * sa + tau * (ugb * ga[i] + pb * guga_a[i]));
                     }
-                    acc[15] += tau * gab;
+                    acc[15] += fv.pspg * tau * gab;
                 }
                 if (b == 0) {                               // residual of node a
                     const double p = Q[3];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
                             Rl[i] += Q[9 + i] * pa + nu * vg[i] - p * ga[i] + tau * uga * (Q[9 + i] + gp[i]) +
                                      nuL * divu * ga[i];
                     }
-                    Rl[3] += pa * divu + tau * sa;
+                    Rl[3] += pa * divu + fv.pspg * tau * sa;
                 }
             }
 #pragma unroll
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(EL_TPB, 3) void k_element(int64_t n_tets, const int
 
 #define SNS_INST_ELEMENT(F, C)                                                                              \
     template __global__ void k_element<F, C>(int64_t, const int32_t*, const double*, const double*,            \
-                                             const uint8_t*, const double*, double, int, double*, double*);
+                                             const uint8_t*, const double*, double, int, double*, double*, FormVariant);
 SNS_INST_ELEMENT(SNS_FORM_STOKES, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, false)
 SNS_INST_ELEMENT(SNS_FORM_NS, true)

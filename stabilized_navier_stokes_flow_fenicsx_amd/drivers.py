@@ -12,9 +12,14 @@
 What is kept: argv, the Stokes -> coarse NS -> fine NS continuation (:513-530),
 boundary-condition sets, solver settings, printed diagnostics, output folder /
 file names.  What differs, because gmsh / skimage / dolfinx do not exist offline
-(SURVEY 8f, next-row 2): an existing inlet PNG is processed on its pixel grid
-(inlet_image.py: regions, Poisson profiles, flow-ratio scaling as image2inlet.py:
-240-339, nozzle walls as no-slip nodes) and drives a structured 4x1x1 box channel;
+(SURVEY 8f, next-row 2): an existing inlet PNG goes through the repository's own
+restatement of the reference's pipeline (inlet_contours.py: marching-squares contours,
+FFT low-pass, RDP, P1 Poisson profiles with the flow-ratio scaling of image2inlet.py:
+240-339) and -- since round 5 -- drives the BODY-FITTED channel of nozzle_mesh.py: the box
+4 x 1 x 1 minus the nozzle wall extruded over x in [0, 0.5], tags inlet_1 / inlet_2 /
+outlet / wall = 1-4, sizes along x after the reference's Box fields
+(image2gmsh3D.py:164-486).  SNS_CHANNEL_MESH=structured selects rounds 2-4's
+structured box with the nozzle wall as staircase no-slip nodes (inlet_image.py).
 ``<img_fname>`` may also be a gmsh ``.msh`` file (tags inlet_1=1, inlet_2=2,
 outlet=3, wall=4); with neither, a centred square inner stream with analytic
 profiles of the same normalisation is used.  DuctStokesFlow keeps
@@ -97,14 +102,19 @@ def create_boundary_conditions(msh, flowrate_ratio):
 
 def channel_problem_inputs(img_fname: str, flowrate_ratio: float, channel_mesh_size: float):
     """(mesh, bcs) of one continuation stage (generate_mesh + create_boundary_conditions, :107-147).
-    An existing image drives the inlet as in image2inlet.py (pixel-grid restatement, inlet_image.py);
+    An existing image drives the inlet as in image2inlet.py + image2gmsh3D.py: contour pipeline, Poisson profiles and the
+    body-fitted nozzle channel (nozzle_mesh.py; SNS_CHANNEL_MESH=structured: the structured box with staircase walls);
     a ``.msh`` file is read as is; anything else falls back to the synthetic centred-square inlet."""
     is_img = img_fname.lower().endswith((".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff")) and os.path.exists(img_fname)
     if is_img:
-        from .inlet_image import channel_from_image
         if _rank() == 0:
             print("Meshing", flush=True)
-        msh, bcs, _ = channel_from_image(img_fname, flowrate_ratio, lc_to_cells(channel_mesh_size))
+        if os.environ.get("SNS_CHANNEL_MESH", "bodyfitted") == "structured":
+            from .inlet_image import channel_from_image
+            msh, bcs, _ = channel_from_image(img_fname, flowrate_ratio, lc_to_cells(channel_mesh_size))
+        else:
+            from .nozzle_mesh import channel_from_image_bodyfitted
+            msh, bcs, _ = channel_from_image_bodyfitted(img_fname, flowrate_ratio, channel_mesh_size)
         if _rank() == 0:
             print(f"Num elem: {msh.num_tets}", flush=True)
         return msh, bcs

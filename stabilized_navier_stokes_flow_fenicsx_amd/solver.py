@@ -228,6 +228,10 @@ class FlowProblem:
             setattr(self.options, k, v)
         check(self.lib.sns_set_options(self.h, C.byref(self.options)))
 
+    def set_form_variant(self, c_inverse=36.0, lsic_scale=1.0, pspg_sign=1.0, one_point_quadrature=False):
+        """DIAGNOSTIC: perturb the 3-D NS form (sns_set_form_variant); the defaults restore the reference's form."""
+        check(self.lib.sns_set_form_variant(self.h, float(c_inverse), float(lsic_scale), float(pspg_sign), int(bool(one_point_quadrature))))
+
     # -- hot path -------------------------------------------------------------
     def residual(self, w, form="ns", out=None) -> torch.Tensor:
         """F(w) as the reference's .F callback leaves it (:51-67)."""

@@ -642,3 +642,64 @@ def test_hessenberg_eigenvalues_match_numpy():
             assert max(np.min(np.abs(ref - e)) for e in ev) < 1e-8 * max(1.0, np.abs(ref).max())
             assert max(np.min(np.abs(ev - e)) for e in ref) < 1e-8 * max(1.0, np.abs(ref).max())
     assert lib.sns_host_hessenberg_eigs(0, None, None, None) != 0
+
+
+@pytest.mark.parametrize("name", ["inlet_PlusF_final.png", "inlet_Triangle.png"])
+def test_bodyfitted_nozzle_channel_geometry(name):
+    """Row f2 at full fidelity: the channel of image2gmsh3D.py:164-486 -- box 4 x 1 x 1 minus the nozzle wall
+    (the band between the two contours of the inlet image) extruded over x in [0, 0.5] (:193-194), tags inlet_1 / inlet_2 /
+    outlet / wall = 1-4 (:435-438), node planes after the three Box fields (:445-483) -- as nozzle_mesh.py builds it: the mesh
+    is conforming (every interior face shared by two tets), its volume is the box minus the extruded band, the tagged surfaces have
+    the areas of the geometry (inlets = the two regions, wall = duct walls + both nozzle surfaces + the band's end face), no node
+    lies inside the wall, and the Dirichlet data carry the flow-rate split."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import nozzle_mesh as NM
+    from stabilized_navier_stokes_flow_fenicsx_amd.inlet_contours import points_in_polygon
+    lc = 0.06
+    m, (mask, g), data = NM.channel_from_image_bodyfitted(os.path.join(ROOT, "tests", "golden", name), 0.4, lc)
+    t = m.meta["tags"]
+    assert t == {"inlet_1": 1, "inlet_2": 2, "outlet": 3, "wall": 4}
+    X = m.points[m.tets]
+    vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))) / 6.0
+    band = 1.0 - data.area_1 - data.area_2
+    assert vol.min() > 1e-9 and abs(vol.sum() - (4.0 - 0.5 * band)) < 2e-3              # (the chains cut the polygon's corners by O(h^2))
+    assert len(np.unique(m.tets)) == m.num_nodes                                          # every node belongs to a tet
+    # conformity: faces shared by exactly two tets, or boundary facets -- _boundary_facets found every boundary face, and their
+    # areas add up to the surface of the geometry
+    def area(f):
+        P = m.points[f]
+        return 0.5 * np.linalg.norm(np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]), axis=1)
+    A = {k: float(area(m.facets[m.facet_tags == v]).sum()) for k, v in t.items()}
+    ci, co = data.contour_inner[:, ::-1], data.contour_outer[:, ::-1]
+    per = lambda c: float(np.linalg.norm(np.roll(c, -1, axis=0) - c, axis=1).sum())
+    assert abs(A["inlet_1"] - data.area_1) < 3e-3 and abs(A["inlet_2"] - data.area_2) < 3e-3 and abs(A["outlet"] - 1.0) < 1e-12
+    wall_expected = 4 * 4.0 * 1.0 + 0.5 * (per(ci) + per(co)) + band
+    assert abs(A["wall"] - wall_expected) < 0.02 * wall_expected, (A["wall"], wall_expected)
+    # nothing inside the wall upstream of the lip; planes at x = 0, 0.5, 4 and the size fields of :445-483 along x
+    up = m.points[m.points[:, 0] < 0.5 - 1e-9]
+    yz = up[:, 1:]
+    inside_band = points_in_polygon(yz, co) & ~points_in_polygon(yz, ci)
+    from scipy.spatial import cKDTree
+    d = cKDTree(np.concatenate([NM.resample_contour(ci, 0.005), NM.resample_contour(co, 0.005)])).query(yz[inside_band])[0] if inside_band.any() else np.zeros(0)
+    assert (d < 0.02).all()                                                               # (only nodes ON the surfaces, up to the corner cuts)
+    xs = np.unique(np.round(m.points[:, 0], 12))
+    assert xs[0] == 0.0 and xs[-1] == 4.0 and np.any(np.abs(xs - 0.5) < 1e-12)
+    dx = np.diff(xs)
+    mid = 0.5 * (xs[1:] + xs[:-1])
+    # (each stretch is rescaled to end on its plane: up to +30 % on the handful of planes upstream of the lip)
+    assert dx[mid < 0.25].max() < 1.0 * lc and dx[(mid > 0.4) & (mid < 0.6)].max() < 0.5 * lc        # 0.75 lc, 0.375 lc
+    assert dx[(mid > 0.75) & (mid < 1.0)].max() < 0.65 * lc and 1.5 * lc < dx[mid > 2.5].max() <= 2.2 * lc   # lc / 2, 2 lc
+    # Dirichlet sets in the reference's order [wall, inlet_1, inlet_2, outlet]; the inlet data carry ratio : 1 - ratio
+    q1, q2, _ = NM.inlet_fluxes(m, g)
+    # (lc = 0.06, cross-section size 0.045: the P1 interpolant of the Poisson profiles on a few hundred inlet triangles, as coarse as
+    # the reference's own non-matching interpolation at that size; 1 % at lc = 0.035, tests/test_gpu_parity.py)
+    assert abs(q1 / 0.4 - 1.0) < 0.12 and abs(q2 / 0.6 - 1.0) < 0.12 and abs(q1 / q2 / (0.4 / 0.6) - 1.0) < 0.06, (q1, q2)
+    wall = m.facet_nodes(t["wall"])
+    G, Mk = g.reshape(-1, 4), mask.reshape(-1, 4)
+    only_wall = np.setdiff1d(wall, np.union1d(m.facet_nodes(t["inlet_1"]), m.facet_nodes(t["inlet_2"])))
+    assert np.all(Mk[only_wall, :3] == 1) and np.all(G[only_wall, :3] == 0.0)
+    out = m.facet_nodes(t["outlet"])
+    assert np.all(Mk[out, 3] == 1) and np.all(G[out, 3] == 0.0)
+    # the driver takes this mesh for an image argument (and the structured box on request)
+    from stabilized_navier_stokes_flow_fenicsx_amd import drivers as D
+    msh, _ = D.channel_problem_inputs(os.path.join(ROOT, "tests", "golden", name), 0.4, 0.2 if name.startswith("inlet_Tri") else 0.15)
+    assert msh.meta["kind"] == "channel-nozzle"
