@@ -127,8 +127,6 @@ typedef struct {
                                nu = 1/Re: LidDrivenNavierStokesFlow.py:96-104) */
     double stokes_beta;     /* 2-D handles only: mu_T = stokes_beta * h^2 (0.2: DFG_2D_Validation.py:104-106;
                                a0/(4 nu), a0 = 1/3: LidDrivenNavierStokesFlow.py:98-100) */
-    int    amg_fine_cycle;  /* shape of the AMG cycle on the fine level (single GPU): 0 = V(1,1) (default),
-                               1 = V(0,1) (no pre-smoothing), 2 = V(1,0) (no post-smoothing) */
     int    amg_nu_l1_pre;   /* sweeps BEFORE the coarse-grid correction on level 1; the first one is omega D^-1 b from the zero
                                guess, no matrix pass.  0 (default) = automatic, see amg_nu_l1_post */
     int    amg_nu_l1_post;  /* sweeps AFTER the coarse-grid correction on level 1.  Both 0 (default) = automatic: a single-GPU
@@ -187,12 +185,6 @@ typedef struct {
                                the limit is amplified by every one of the level's sweeps (jittered 120 x 30 x 30 duct, Re 200:
                                level 1 at w = 0.68 against a limit of 0.45 stalls BiCGStab; oracle/experiments/r4_damping.py).
                                0: the |lambda|max rule alone */
-    int    amg_growth_check; /* the growth check of the damping (six trial sweeps on the power iteration's dominant mode, w scaled by 0.9
-                               until a sweep contracts it by 10 %): 2 (rounds 1-3) = every level, 1 (default) = only levels that run
-                               >= 3 sweeps per cycle, 0 = never.  A level with two sweeps per cycle (the fine level) does not compound
-                               an amplified mode; backing its damping off for a few complex outliers costs smoothing everywhere else
-                               (jittered 120 x 30 x 30 duct, Re 200: 56 iterations with 1, 82 with 2, 85 with 0; no difference on
-                               BASELINE configs 3 / 4 / 4u / 5) */
     int    amg_block_max_rows; /* aggregate blocks only on levels with at most this many rows per rank; 0 (default) = no limit.  (While the
                                inverse blocks were fp32 -- 4 KiB per aggregate -- a block sweep cost 1.5x a nodal sweep on a large
                                level and the limit was 8192; in the format of the level's fp16 matrix copy, 2 KiB + row scales, it
@@ -214,6 +206,8 @@ typedef struct {
                                the neighbours' arrival flags themselves: no unpack kernel, no interior / boundary split, no second
                                stream, no staging copies.  0 = put + wait / unpack into the vector's ghost tail, then the passes of
                                round 4 (the RCCL transport always works that way, with pack + send / recv + unpack) */
+    /* (retired in round 5, VERDICT r4 item 6: amg_fine_cycle -- the experimental V(0,1) / V(1,0) fine-level cycles, never the default
+       and untested since round 3 --, amg_growth_check -- its value 1 is the rule now, csrc/sns_setup.hip) */
     int    amg_exact_sweeps; /* (round 5) 1 (default): on the window transports the aggregate-block-smoothed PARTITIONED levels >= 1 run
                                the single-GPU schedule (level 1: 1 + amg_bnu_l1 sweeps, the coarse-grid correction inside the first
                                post-sweep) with EXACT global sweeps -- one put per sweep, which costs one small launch there --
@@ -465,6 +459,17 @@ SNS_API int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int
  * (MatMult's VecScatter overlap in the reference's PETSc).  rows_out [n_owned], *n_out entries are valid.        */
 SNS_API int sns_host_boundary_rows(int32_t n_owned, const int32_t* rowptr, const int32_t* colind,
                            int32_t* rows_out, int32_t* n_out);
+
+/* The policy table of the AMG hierarchy on its own (csrc/sns_policy.h: the ONE place that holds its size thresholds and sweep
+ * schedules): for a hierarchy of `nlevels` levels with rows_global[l] rows (a replicated level: its rows) on `nranks` ranks --
+ * rep_level = first level held redundantly by every rank (0: none; the level before it is only the source of the copy and gets
+ * kind -1), windows != 0: a window transport (peer / team), rows_global_l1 = rows of level 1 as coarsened (decides the
+ * unstructured tier of amg_nu_scale_with_size), has_blocks[l] (NULL: all 1) = the level's aggregates fit the 32 x 32 smoother
+ * blocks -- the smoother / solver kind (SNS_LEVEL_*), the sweeps before and after the coarse-grid correction and whether the
+ * level's sweeps are the exact global ones (amg_exact_sweeps).  What sns_get_cycle reports of a handle of that shape.            */
+SNS_API int sns_host_cycle_policy(const sns_options* opt, int nranks, int windows, int nlevels, const int64_t* rows_global,
+                                  int rep_level, int64_t rows_global_l1, const uint8_t* has_blocks, int32_t* kind,
+                                  int32_t* nu_pre, int32_t* nu_post, int32_t* exact);
 
 /* eigenvalues of a small real upper-Hessenberg matrix (row-major n x n, n <= 32; entries below the first subdiagonal ignored):
  * the Ritz values of the short Arnoldi process that caps the smoother damping (amg_ritz_limit).                          */

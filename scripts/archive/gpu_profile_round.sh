@@ -1,14 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash scripts/gpu_profile_round4.sh r4h
-# the round's profile: un-profiled default bench (incl. CPU baseline and the all-fp64 repetition), kernel stats under rocprofv3,
-# FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only), trimmed to the fine-level family + assembly
+# usage (on the GPU box, from the repo root): bash scripts/gpu_profile_round.sh r1e
 set -e
 tag=$1
 R=$(pwd)
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 python bench.py > $out/${tag}_bench_unprofiled.json 2> $out/bench.err
-echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f64-rerun > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
 echo "stats done"

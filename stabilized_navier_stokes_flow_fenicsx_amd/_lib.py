@@ -32,7 +32,6 @@ class SnsOptions(C.Structure):
         ("amg_coarse_size", C.c_int), ("amg_agg_size", C.c_int), ("amg_nu", C.c_int),
         ("amg_omega", C.c_double), ("monitor", C.c_int), ("corrected_convection", C.c_int), ("amg_f32_matrix", C.c_int), ("amg_nu_coarse", C.c_int), ("amg_nu_deep", C.c_int), ("amg_nu_l2", C.c_int), ("amg_sweep_exchange_rows", C.c_int), ("amg_replicate_rows", C.c_int), ("amg_post_exchange", C.c_int), ("assembly_fused", C.c_int),
         ("stokes_viscosity", C.c_double), ("stokes_beta", C.c_double),
-        ("amg_fine_cycle", C.c_int),
         ("amg_nu_l1_pre", C.c_int),
         ("amg_nu_l1_post", C.c_int),
         ("amg_retry_damping", C.c_int),
@@ -46,7 +45,6 @@ class SnsOptions(C.Structure):
         ("amg_bnu_l2", C.c_int),
         ("amg_bnu_deep", C.c_int),
         ("amg_ritz_limit", C.c_int),
-        ("amg_growth_check", C.c_int),
         ("amg_block_max_rows", C.c_int),
         ("amg_block_fine_rows", C.c_int),
         ("amg_fuse_restrict", C.c_int),
@@ -130,6 +128,7 @@ _SIGNATURES = [
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
     ("sns_host_boundary_rows", C.c_int, [C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
+    ("sns_host_cycle_policy", C.c_int, [C.POINTER(SnsOptions), C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P]),
     ("sns_host_hessenberg_eigs", C.c_int, [C.c_int, _P, _P, _P]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -220,3 +219,19 @@ def host_boundary_rows(n_owned: int, rowptr, colind):
     n = C.c_int32()
     check(lib.sns_host_boundary_rows(n_owned, rowptr.ctypes.data, colind.ctypes.data, out.ctypes.data, C.byref(n)))
     return out[:n.value].copy()
+
+
+def host_cycle_policy(rows_global, nranks=1, windows=False, rep_level=0, rows_global_l1=None, has_blocks=None, **opt_kw):
+    """The hierarchy's policy table (sns_host_cycle_policy, csrc/sns_policy.h) for a hierarchy of the given shape: a list of
+    dict(kind, pre, post, exact) per level (kind -1: the source of the replicated copy, not cycled).  No GPU needed."""
+    import numpy as np
+    lib = load()
+    o = default_options(**opt_kw)
+    rows = np.ascontiguousarray(rows_global, dtype=np.int64)
+    n = len(rows)
+    hb = np.ones(n, np.uint8) if has_blocks is None else np.ascontiguousarray(has_blocks, dtype=np.uint8)
+    kind, pre, post, ex = (np.zeros(n, np.int32) for _ in range(4))
+    l1 = int(rows[1]) if rows_global_l1 is None and n > 1 else int(rows_global_l1 or 0)
+    check(lib.sns_host_cycle_policy(C.byref(o), int(nranks), int(bool(windows)), n, rows.ctypes.data, int(rep_level), l1,
+                                    hb.ctypes.data, kind.ctypes.data, pre.ctypes.data, post.ctypes.data, ex.ctypes.data))
+    return [dict(kind=int(kind[l]), pre=int(pre[l]), post=int(post[l]), exact=int(ex[l])) for l in range(n)]

@@ -272,6 +272,47 @@ __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* 
 template __global__ void k_bfirst<1>(int32_t, const int32_t*, const void*, const double*, double, double*);
 template __global__ void k_bfirst<2>(int32_t, const int32_t*, const void*, const double*, double, double*);
 
+// First sweep of the REPLICATED tail's first level with the wait half of the all-gather of its right-hand side inside: row g of the
+// level is piece rowmap[g] (= rank * maxn + i) of the gathered vector, read from this rank's staging area once every rank's flag
+// of the round has arrived; b_out gets the right-hand side for the sweeps that follow.  The last workgroup stores the round.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_bfirst_gather(int32_t n_slots, const int32_t* __restrict__ blk_rows,
+                                                       const void* __restrict__ binv, double omega, double* __restrict__ z,
+                                                       double* __restrict__ b_out, const int32_t* __restrict__ rowmap, AgGet ag) {
+    __shared__ double sres[8 * 32];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
+    const unsigned long long seq = __hip_atomic_load(ag.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    if (ag.flags) {
+        if (tid < ag.nranks) (void)peer_flag_wait(&ag.ctl->ag_flag[tid], seq, ag.timeout_ticks, ag.err, 3);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    const double* __restrict__ src = ag.stage + (int64_t)(seq & 1ull) * ag.stage_doubles;
+    const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
+    const bool in = slot < n_slots;
+    const int32_t row = in ? blk_rows[slot] : -1;
+    const bool live = row >= 0;
+    BinvRow<FMT> Bv;
+    Bv.load(binv, slot >> 3, j, in);
+    double bv = 0.0;
+    if (live) {
+        bv = src[4 * (int64_t)rowmap[row] + c];
+        b_out[4 * (int64_t)row + c] = bv;
+    }
+    const double zz = block_apply(Bv, bv, sres + 32 * (tid >> 5), j);
+    if (live) z[4 * (int64_t)row + c] = omega * zz;
+    __syncthreads();
+    if (tid == 0) last = (atomicAdd(ag.done, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (last && tid == 0) {
+        *ag.done = 0u;
+        __hip_atomic_store(ag.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template __global__ void k_bfirst_gather<1>(int32_t, const int32_t*, const void*, double, double*, double*, const int32_t*, AgGet);
+template __global__ void k_bfirst_gather<2>(int32_t, const int32_t*, const void*, double, double*, double*, const int32_t*, AgGet);
+
 // The FINE level's first sweep (aggregate blocks: partitioned handles of the strong split, amg_block_fine_rows) inside the BiCGStab
 // vector kernel that produces the cycle's input -- what k_bicg_s_first / k_bicg_xrp_first are to the nodal blocks: one dependent
 // launch and one read of the input less per cycle.  The dofs are walked in the order of the aggregates (every owned node is in
@@ -380,11 +421,14 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
                                                         const double* __restrict__ bvec, double* __restrict__ r_out,
                                                         double* __restrict__ bc, const float* __restrict__ dinv32_c,
                                                         const void* __restrict__ binv_c, double omega_c, double* __restrict__ z_c,
-                                                        GhostSrc gs) {
+                                                        GhostSrc gs, AgPut agp) {
     __shared__ double sred[8][8][4];
     __shared__ double sbc[32];
     GhostReader gr;
     if (GH) gr.begin(gs);
+    // (agp: the restricted right-hand side also goes into every rank's all-gather staging area -- the level below is the source
+    // of a partitioned run's replicated tail -- and the last workgroup raises this rank's flag there)
+    const unsigned long long ag_seq = agp.ag ? __hip_atomic_load(agp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull : 0ull;
     const int tid = threadIdx.x, hw = tid >> 5, q = (tid & 31) >> 2, c = tid & 3;
     const int32_t G = (int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x);          // the coarse smoother block of this workgroup
     const int32_t slot = G * 8 + hw;
@@ -415,7 +459,27 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
         }
         __syncthreads();
     }
-    if (q == 0 && I >= 0) bc[4 * (int64_t)I + c] = s;
+    if (q == 0 && I >= 0) {
+        bc[4 * (int64_t)I + c] = s;
+        if (agp.ag) {
+            const int64_t o = (int64_t)(ag_seq & 1ull) * agp.stage_doubles + (int64_t)agp.rank * agp.slot_doubles + 4 * (int64_t)I + c;
+            for (int r = 0; r < agp.nranks; ++r) agp.ag[r][o] = s;
+        }
+    }
+    if (agp.ag) {
+        __shared__ int ag_last;
+        if (agp.flags) __threadfence_system();
+        __syncthreads();
+        if (tid == 0) ag_last = (atomicAdd(agp.done, 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (ag_last) {
+            if (agp.flags) {
+                __threadfence_system();
+                if (tid < agp.nranks) peer_flag_store(&agp.ctl[tid]->ag_flag[agp.rank], ag_seq);
+            }
+            if (tid == 0) *agp.done = 0u;
+        }
+    }
     if (MODE == 1) {
         if (q == 0 && I >= 0) {                                                      // whole quads: the four sums of the node
             const float4 D = *reinterpret_cast<const float4*>(dinv32_c + 16 * (int64_t)I + 4 * c);
@@ -437,7 +501,7 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
     template __global__ void k_resid_restrict<F, M, G>(int32_t, int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, \
                                                        const int32_t*, const int32_t*, const void*, const float*, const double*,    \
                                                        const double*, double*, double*, const float*, const void*, double, double*, \
-                                                       GhostSrc);
+                                                       GhostSrc, AgPut);
 SNS_INST_RR(1, 0, 0) SNS_INST_RR(1, 1, 0) SNS_INST_RR(1, 2, 0) SNS_INST_RR(2, 0, 0) SNS_INST_RR(2, 1, 0) SNS_INST_RR(2, 2, 0)
 SNS_INST_RR(1, 0, 1) SNS_INST_RR(1, 1, 1) SNS_INST_RR(1, 2, 1) SNS_INST_RR(2, 0, 1) SNS_INST_RR(2, 1, 1) SNS_INST_RR(2, 2, 1)
 #undef SNS_INST_RR

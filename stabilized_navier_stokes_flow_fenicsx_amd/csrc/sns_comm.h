@@ -119,6 +119,9 @@ int comm_allgather(Comm* c, const double* send_dev, double* recv_dev, int count,
 // in the order of its rows, no gather kernel behind it
 int comm_allgatherv(Comm* c, const double* send_dev, double* recv_dev, int max_count, const int64_t* dev_off,
                     const int64_t* dev_cnt, hipStream_t s);
+// the two halves of an all-gather carried by solver kernels (sns_peer_dev.h: AgPut / AgGet); slot = doubles per rank
+AgPut comm_ag_put(const Comm* c, int64_t slot_doubles);
+AgGet comm_ag_get(const Comm* c);
 // team transport: wait for this rank's stream, then for every rank (no-op otherwise).  The window transports' two-phase
 // collectives call it between their halves.
 int comm_host_barrier(Comm* c, hipStream_t s);

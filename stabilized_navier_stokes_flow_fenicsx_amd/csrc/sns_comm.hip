@@ -350,6 +350,37 @@ int peer_allgather_chunk(Comm* c, const double* send, double* recv, int64_t coun
 }
 }  // namespace
 
+AgPut comm_ag_put(const Comm* c, int64_t slot_doubles) {
+    AgPut a;
+    if (!c || !c->peer) return a;
+    const Peer* pe = c->peer;
+    a.ag = pe->d_ag;
+    a.ctl = pe->d_ctl;
+    a.seq = pe->d_seq + 1;
+    a.done = pe->d_done + PEER_MAX_RANKS + 1;
+    a.rank = pe->rank;
+    a.nranks = pe->nranks;
+    a.flags = pe->host_sync ? 0 : 1;
+    a.stage_doubles = (long long)pe->ag_doubles;
+    a.slot_doubles = (long long)slot_doubles;
+    return a;
+}
+AgGet comm_ag_get(const Comm* c) {
+    AgGet g;
+    if (!c || !c->peer) return g;
+    const Peer* pe = c->peer;
+    g.stage = reinterpret_cast<const double*>(pe->base[pe->rank] + pe->ag_off);
+    g.ctl = reinterpret_cast<const PeerCtl*>(pe->base[pe->rank]);
+    g.seq = pe->d_seq + 1;
+    g.done = pe->d_done + PEER_MAX_RANKS;
+    g.nranks = pe->nranks;
+    g.flags = pe->host_sync ? 0 : 1;
+    g.stage_doubles = (long long)pe->ag_doubles;
+    g.err = pe->err_dev;
+    g.timeout_ticks = pe->timeout_ticks;
+    return g;
+}
+
 int comm_allgather(Comm* c, const double* send, double* recv, int count, hipStream_t s) {
     if (!c || !c->active() || c->nranks <= 1) {
         CHIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -424,8 +455,8 @@ int peer_create(int device, int rank, int nranks, size_t window_bytes, Peer** ou
     CHIP(hipHostMalloc((void**)&p->err_host, sizeof(int), hipHostMallocMapped));
     *p->err_host = 0;
     CHIP(hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0));
-    CHIP(hipMalloc((void**)&p->d_done, (PEER_MAX_RANKS + 1) * sizeof(unsigned int)));
-    CHIP(hipMemset(p->d_done, 0, (PEER_MAX_RANKS + 1) * sizeof(unsigned int)));
+    CHIP(hipMalloc((void**)&p->d_done, (PEER_MAX_RANKS + 2) * sizeof(unsigned int)));
+    CHIP(hipMemset(p->d_done, 0, (PEER_MAX_RANKS + 2) * sizeof(unsigned int)));
     CHIP(hipMalloc((void**)&p->d_seq, 2 * sizeof(unsigned long long)));
     CHIP(hipMemset(p->d_seq, 0, 2 * sizeof(unsigned long long)));
     double ms = 20000.0;

@@ -1,0 +1,499 @@
+// The V-cycle (serial, partitioned over RCCL, partitioned over the window transports), the hipGraph of its launch-bound tail,
+// and the preconditioner / operator applications the Krylov methods call.
+// (round 5: one of the four translation units csrc/sns_api.hip was split into; shared internals in csrc/sns_ctx.h)
+#include "sns_ctx.h"
+
+namespace sns {
+
+// Coarse part of the cycle (the graph level and below) as ONE hipGraph launch.  Captured on a private
+// stream (the caller's stream may be the legacy default stream, which cannot be captured), re-captured when
+// the per-level damping or the cycle shape changed.  Distributed runs keep direct launches (the exchange
+// inside the cycle is a host-driven RCCL group).  Any capture failure disables the graph for good.
+int coarse_cycle(sns_ctx* h, int l, const double* b, double* x) {
+    const bool dist = h->comm && h->comm->active() && h->comm->nranks > 1;
+    // distributed runs: only the replicated tail is free of exchanges and can be captured
+    const int gl = dist ? h->rep_level : serial_graph_level(h);
+    if (gl <= 0 || l != gl || h->graph_disabled || (int)h->levels.size() <= gl + 1) return vcycle(h, l, b, x);
+    std::vector<double> sig;
+    for (auto& L : h->levels) sig.push_back(L.omega);
+    sig.push_back(h->opt.amg_nu); sig.push_back(h->opt.amg_nu_coarse); sig.push_back(h->opt.amg_nu_deep);
+    sig.push_back(h->opt.amg_nu_l2);
+    sig.push_back(h->opt.amg_nu_l1_pre); sig.push_back(h->opt.amg_nu_l1_post);
+    sig.push_back(h->opt.amg_f32_matrix);
+    sig.push_back(h->opt.amg_fused_post);
+    sig.push_back(h->opt.amg_nu_scale_with_size);
+    sig.push_back(h->opt.amg_block_smooth); sig.push_back(h->opt.amg_bnu_l1); sig.push_back(h->opt.amg_bnu_l2);
+    sig.push_back(h->opt.amg_bnu_deep); sig.push_back(h->opt.amg_block_max_rows); sig.push_back(h->opt.amg_block_fine_rows);
+    sig.push_back(h->opt.amg_fuse_restrict);
+    sig.push_back(restrict_fuses_first(h, gl - 1) ? 1.0 : 0.0);
+    sig.push_back(rep_gather_first(h) ? 1.0 : 0.0);
+    sig.push_back(gl);
+    if (!h->coarse_graph || sig != h->graph_sig) {
+        if (h->coarse_graph) { (void)hipGraphExecDestroy(h->coarse_graph); h->coarse_graph = nullptr; }
+        if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+            h->graph_disabled = true;
+            return vcycle(h, l, b, x);
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));          // capture must not race with pending work on the buffers
+        hipStream_t user = h->stream;
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            h->stream = h->cap_stream;
+            const int rc = vcycle(h, l, b, x);
+            h->stream = user;
+            ok = (hipStreamEndCapture(h->cap_stream, &graph) == hipSuccess) && rc == SNS_OK && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&h->coarse_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {
+            (void)hipGetLastError();
+            h->coarse_graph = nullptr;
+            h->graph_disabled = true;
+            return vcycle(h, l, b, x);
+        }
+        h->graph_sig = sig;
+    }
+    HIP_TRY(hipGraphLaunch(h->coarse_graph, h->stream));
+    return SNS_OK;
+}
+
+
+// The V-cycle of a PARTITIONED level over a window transport (peer windows / the in-process team; round 5).  Every exchange is one
+// put launch (comm_put) and the pass behind it reads the ghost entries from the level's receive window, its boundary waves waiting
+// for the neighbours themselves: no staging copy, no unpack, no split pass.  Level 0: first sweep | put, residual | restriction
+// (+ level 1's first sweep) | coarse | put of level 1's solution, fused correction + post-sweep.  Level >= 1 (level_exact): the
+// single-GPU schedule with exact global sweeps -- [put, sweep]* | put, residual + restriction (+ next first sweep) in one launch |
+// coarse | fused correction + first post-sweep (the coarse solution read straight from the replicated tail where that is the next
+// level, else after a put of it) | [put, sweep]*.
+int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
+    Level& L = h->levels[l];
+    Level& C = h->levels[l + 1];
+    Comm* c = h->comm.get();
+    const Plan& P = c->plans[l];
+    const int32_t rows = L.n_owned;
+    const double om = L.omega;
+    int nu_pre = 1, nu_post = 1;
+    level_sweeps(h, l, nu_pre, nu_post);
+    double* cur = cycle_start_buffer(h, l, x);
+    double* oth = (cur == x) ? h->pong[l] : x;
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1)) && !(l == 0 && h->first_sweep_done))
+        launch_first_sweep(h, l, L, rows, b, om, cur);
+    if (l == 0) h->first_sweep_done = false;
+    for (int s = 1; s < nu_pre; ++s) {                     // (level >= 1 only: the fine level runs one sweep per half cycle)
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, P, cur, h->stream));
+        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        std::swap(cur, oth);
+    }
+    const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
+    double* cb = rep_src ? h->rep_bsend : C.b;
+    const double* cx = rep_src ? h->levels[h->rep_level].x + 4 * (size_t)h->rep_off : C.x;
+    const bool fuse = restrict_fuses_first(h, l);
+    const float* dc = fuse ? C.dinv32 : nullptr;
+    double* zc = fuse ? cycle_start_buffer(h, l + 1, C.x) : nullptr;
+    const int fmt = lp_format(h, L);
+    // residual (+ restriction): the true residual needs the neighbours' iterate
+    ++h->ctr_exchange;
+    SNS_TRY(comm_put(c, P, cur, h->stream));
+    const GhostSrc gs = comm_ghost_src(c, P);
+    if (l == 0) {
+        Split s3;
+        s3.mode = 3;
+        s3.gs = gs;
+        if (rows > 0) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0, s3);
+        if (C.n_owned > 0) {
+            if (fuse && block_active(h, 1)) {
+                const int32_t ns = 8 * C.n_blk;
+                if (C.binv_fmt == 2)
+                    hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                else
+                    hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+            } else {
+                hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                                   C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
+            }
+        }
+    } else if (rows > 0 && C.n_owned > 0) {
+        // (the level below is the source of the replicated tail: the restricted right-hand side goes straight into every rank's
+        // all-gather staging area, the tail's first sweep waits for it -- rep_gather_first)
+        const AgPut agp = (rep_src && rep_gather_first(h)) ? comm_ag_put(c, 4 * (int64_t)h->rep_maxn) : AgPut();
+        const int mode = !fuse ? 0 : (block_active(h, l + 1) ? 2 : 1);
+        const int32_t* slots = mode == 2 ? C.blk_rows : nullptr;
+        const int32_t n_slots = mode == 2 ? 8 * C.n_blk : C.n_owned;
+        const unsigned grid = (unsigned)((n_slots + 7) / 8);
+        const void* vals = fmt == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
+        const float* sc16 = fmt == 2 ? L.scale16 : nullptr;
+#define SNS_RRW(F, M)                                                                                                              \
+    hipLaunchKernelGGL((k_resid_restrict<F, M, 1>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, (const double*)cur, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, gs, agp)
+        if (fmt == 2) { if (mode == 2) SNS_RRW(2, 2); else if (mode == 1) SNS_RRW(2, 1); else SNS_RRW(2, 0); }
+        else          { if (mode == 2) SNS_RRW(1, 2); else if (mode == 1) SNS_RRW(1, 1); else SNS_RRW(1, 0); }
+#undef SNS_RRW
+    }
+    SNS_TRY(coarse_cycle(h, l + 1, cb, rep_src ? nullptr : C.x));
+    // fused coarse-grid correction + first post-smoothing sweep over M = A P; the ghost aggregates' part of the coarse solution:
+    // level >= 1 above the replicated tail reads every entry from the replicated solution (M's columns renumbered into its ids,
+    // ap_colind_rep), else one put of the coarse level's solution and the window behind it
+    GhostSrc gc;
+    const double* xc = cx;
+    const int32_t* apc = L.ap_colind;
+    if (rep_src && l >= 1) {
+        xc = h->levels[h->rep_level].x;
+        apc = L.ap_colind_rep;
+    } else {
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, c->plans[l + 1], cx, h->stream));
+        gc = comm_ghost_src(c, c->plans[l + 1]);
+    }
+    if (rows > 0) {
+        if (l == 0) time_begin(h, 4);
+        if (block_active(h, l) && L.binv32) {
+            const int32_t ns = 8 * L.n_blk;
+            const unsigned gb = (unsigned)((ns + 63) / 64);
+            const void* mv = fmt == 2 ? (const void*)L.ap_vals16 : (const void*)L.ap_vals32;
+            const float* ms = fmt == 2 ? L.ap_scale16 : nullptr;
+#define SNS_BPW(F, G)                                                                                                          \
+    hipLaunchKernelGGL((k_bpost<F, G>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, apc, mv, ms,             \
+                       (const void*)L.binv32, xc, cx, (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, gc)
+            if (gc.win[0]) { if (fmt == 2) SNS_BPW(2, 1); else SNS_BPW(1, 1); }
+            else           { if (fmt == 2) SNS_BPW(2, 0); else SNS_BPW(1, 0); }
+#undef SNS_BPW
+        } else {
+            const int grid = (rows + 63) / 64;             // (nodal blocks: the fine level only, see level_exact)
+            if (fmt == 2)
+                hipLaunchKernelGGL((k_post_lp<2, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind, L.ap_vals16,
+                                   L.ap_scale16, xc, (const double*)cur, (const double*)L.r, L.dinv32, om, L.agg, L.free_mask, oth, gc);
+            else
+                hipLaunchKernelGGL((k_post_lp<1, 2>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                   (const void*)L.ap_vals32, (const float*)nullptr, xc, (const double*)cur, (const double*)L.r, L.dinv32,
+                                   om, L.agg, L.free_mask, oth, gc);
+        }
+        if (l == 0) time_end(h);
+    }
+    std::swap(cur, oth);
+    for (int s = 1; s < nu_post; ++s) {
+        ++h->ctr_exchange;
+        SNS_TRY(comm_put(c, P, cur, h->stream));
+        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        std::swap(cur, oth);
+    }
+    // cur == x by construction of the start buffer
+    return SNS_OK;
+}
+
+
+// V-cycle on level l: x <- approx A_l^-1 b  (x overwritten; zero initial guess)
+int vcycle(sns_ctx* h, int l, const double* b, double* x) {
+    Level& L = h->levels[l];
+    const int32_t rows = L.n_owned;
+    const bool last = (l + 1 == (int)h->levels.size());
+    const double om = L.omega;
+    const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
+    if (h->rep_level > 0 && l == h->rep_level - 1) {
+        // all-gather the right-hand side, cycle the replicated tail, keep my rows of the result
+        Level& C = h->levels[h->rep_level];
+        if (rows > 0 && b != h->rep_bsend)                   // (vcycle of the level above restricts straight into rep_bsend)
+            HIP_TRY(hipMemcpyAsync(h->rep_bsend, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        Comm* cm = h->comm.get();
+        if (rep_gather_first(h)) {
+            // both halves of the all-gather ride in solver kernels: the residual + restriction of the level above has stored this
+            // rank's piece into every rank's staging area, the first sweep of the replicated level waits for the pieces itself
+            SNS_TRY(peer_check(cm));
+            SNS_TRY(comm_host_barrier(cm, h->stream));
+            const int32_t ns = 8 * C.n_blk;
+            double* zc = cycle_start_buffer(h, h->rep_level, C.x);
+            if (C.binv_fmt == 2)
+                hipLaunchKernelGGL((k_bfirst_gather<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   (const void*)C.binv32, C.omega, zc, C.b, h->rep_rowmap, comm_ag_get(cm));
+            else
+                hipLaunchKernelGGL((k_bfirst_gather<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   (const void*)C.binv32, C.omega, zc, C.b, h->rep_rowmap, comm_ag_get(cm));
+        } else if (cm->windows() && h->opt.halo_windows && h->rep_doff &&
+            (size_t)4 * h->rep_maxn * (size_t)cm->nranks <= cm->peer->ag_doubles) {
+            // (every rank's rows land where the replicated level keeps them: no gather kernel behind the all-gather)
+            SNS_TRY(comm_allgatherv(cm, h->rep_bsend, C.b, 4 * h->rep_maxn, h->rep_doff, h->rep_dcnt, h->stream));
+        } else {
+            SNS_TRY(comm_allgather(cm, h->rep_bsend, h->rep_brecv, 4 * h->rep_maxn, h->stream));
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((4 * (int64_t)h->rep_NG + 255) / 256)), dim3(256), 0, h->stream,
+                               h->rep_NG, h->rep_rowmap, h->rep_brecv, C.b);
+        }
+        SNS_TRY(coarse_cycle(h, h->rep_level, C.b, C.x));
+        if (rows > 0 && x)                                   // (x == nullptr: the caller reads its rows of C.x in place)
+            HIP_TRY(hipMemcpyAsync(x, C.x + 4 * (size_t)h->rep_off, 4 * (size_t)rows * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        return SNS_OK;
+    }
+    if (last) {
+        if (h->cg_N > 0) {
+            const int N = h->cg_N, mr = 4 * h->cg_maxn;
+            HIP_TRY(hipMemsetAsync(h->cg_send, 0, mr * sizeof(double), h->stream));
+            if (rows > 0)
+                HIP_TRY(hipMemcpyAsync(h->cg_send, b, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice,
+                                       h->stream));
+            SNS_TRY(comm_allgather(h->comm.get(), h->cg_send, h->cg_recv, mr, h->stream));
+            if (rows > 0)
+                hipLaunchKernelGGL(k_dense_matvec, dim3((4 * rows + 3) / 4), dim3(256), 0, h->stream, N,
+                                   h->cg_full + (size_t)h->comm->rank * mr * N, h->cg_recv, x, 4 * rows);
+            return SNS_OK;
+        }
+        if (L.dense_inv) {
+            const int N = 4 * L.n;
+            hipLaunchKernelGGL(k_dense_matvec, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_inv, b, x, N);
+            return SNS_OK;
+        }
+        if (L.dense_x32) {
+            const int N = 4 * L.n;
+            hipLaunchKernelGGL(k_dense_matvec32, dim3((N + 3) / 4), dim3(256), 0, h->stream, N, L.dense_np, L.dense_x32, b, x);
+            return SNS_OK;
+        }
+        // coarsest level too large for the dense solve: a fixed number of Jacobi sweeps (still a linear operator)
+        double* cur = x;
+        double* oth = h->pong[l];
+        if (rows == 0) return SNS_OK;
+        hipLaunchKernelGGL(k_bjacobi, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv, b, om, cur);
+        for (int s = 0; s < 8; ++s) {       // even count: result ends in x
+            launch_pc_spmv<SPMV_JACOBI>(h, L, rows, cur, oth, b, om);
+            std::swap(cur, oth);
+        }
+        return SNS_OK;
+    }
+    if (level_windows(h, l)) return vcycle_windows(h, l, b, x);
+    const int nu = level_nu(h, l);
+    int nu_pre = nu, nu_post = nu;
+    level_sweeps(h, l, nu_pre, nu_post);
+    double* cur = cycle_start_buffer(h, l, x);
+    double* oth = (cur == x) ? h->pong[l] : x;
+    // distributed: on levels with few rows per rank the sweeps see the neighbours' current iterate (one small
+    // exchange per sweep); on the big levels they stay rank-local (ghost values zero) and only the residual is exact
+    const bool sx = level_sx(h, L);
+    // ... and the sweeps AFTER the coarse-grid correction take the neighbours' corrected iterate as (frozen) ghost
+    // values: with zero ghosts they would see the whole correction as a residual along the partition interfaces
+    const bool px = level_px(h, l, L);
+    const size_t ghost4 = 4 * (size_t)(L.n - rows);
+    const bool tails_unused = (l == 0) && fine_tails_unused(h);
+    if (px && ghost4 > 0 && !tails_unused) {
+        HIP_TRY(hipMemsetAsync(cur + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(oth + 4 * (size_t)rows, 0, ghost4 * sizeof(double), h->stream));
+    }
+    // first sweep from a zero guess: z = omega D^-1 b, with the D^-1 copy the other sweeps of this level read (already done
+    // by the restriction kernel of the level above where restrict_fuses_first says so)
+    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1)) && !(l == 0 && h->first_sweep_done) &&
+        !(h->rep_level > 0 && l == h->rep_level && rep_gather_first(h)))
+        launch_first_sweep(h, l, L, rows, b, om, cur);
+    if (l == 0) h->first_sweep_done = false;
+    for (int s = 1; s < nu_pre; ++s) {
+        if (sx) SNS_TRY(exchange_level(h, l, cur));
+        launch_sweep(h, l, L, rows, cur, oth, b, om);
+        std::swap(cur, oth);
+    }
+    Level& C = h->levels[l + 1];
+    // Below the fine level the residual and the restriction (+ the next level's first sweep) are ONE launch (k_resid_restrict):
+    // `xres` is then the vector the residual reads and the pass itself is issued with the restriction further down.
+    const int fmt_rr = lp_format(h, L);
+    // (amg_fuse_restrict = 2: a single-GPU fine level as well -- its residual kernel is the tuned k_spmv_lp, kept by default)
+    const bool rr_level = l >= 1 || (h->opt.amg_fuse_restrict >= 2 && !L.xg);
+    const bool rr_fused = rr_level && h->opt.amg_fuse_restrict != 0 && fmt_rr != 0 && rows > 0 && C.n_owned > 0 && L.m_ptr &&
+                          (!block_active(h, l + 1) || !restrict_fuses_first(h, l) || C.binv_fmt == fmt_rr);
+    const double* xres = cur;
+    if (sx) {
+        SNS_TRY(exchange_level(h, l, cur));
+        if (!rr_fused) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
+    } else if (L.xg && tails_unused) {
+        // (fine level, fused post-sweep: the halo lands in the iterate's own ghost tail, no copy into the exchange vector)
+        SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, cur, cur, L.r, b, 0.0, nullptr, true));
+    } else if (L.xg) {      // true residual needs the neighbours' iterate
+        HIP_TRY(hipMemcpyAsync(L.xg, cur, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (l == 0) {
+            SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, L.xg, L.xg, L.r, b, 0.0, nullptr, true));
+        } else {
+            SNS_TRY(exchange_level(h, l, L.xg));
+            xres = L.xg;
+            if (!rr_fused) launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, L.xg, L.r, b, 0.0);
+        }
+    } else if (!rr_fused) {
+        launch_pc_spmv<SPMV_B_MINUS_AX>(h, L, rows, cur, L.r, b, 0.0);
+    }
+    // the level below is only the source of the replicated tail: its right-hand side is restricted straight into the all-gather's
+    // send buffer, and the correction is prolongated straight from this rank's rows of the replicated solution (no copies)
+    const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
+    double* cb = rep_src ? h->rep_bsend : C.b;
+    const double* cx = rep_src ? h->levels[h->rep_level].x + 4 * (size_t)h->rep_off : C.x;
+    if (C.n_owned > 0) {
+        // the restriction also does the next level's first sweep (z = w Dc^-1 bc into the buffer that level starts from)
+        const float* dc = nullptr;
+        double* zc = nullptr;
+        const bool fuse = restrict_fuses_first(h, l);
+        if (fuse) {
+            dc = C.dinv32;
+            zc = cycle_start_buffer(h, l + 1, C.x);          // (coarse_cycle below is called with x = C.x)
+        }
+        if (rr_fused) {
+            // mode of the coarse level's first sweep: 0 none, 1 nodal D^-1, 2 its aggregate blocks (walked in THEIR order)
+            const int mode = !fuse ? 0 : (block_active(h, l + 1) ? 2 : 1);
+            const int32_t* slots = mode == 2 ? C.blk_rows : nullptr;
+            const int32_t n_slots = mode == 2 ? 8 * C.n_blk : C.n_owned;
+            const unsigned grid = (unsigned)((n_slots + 7) / 8);
+            const void* vals = fmt_rr == 2 ? (const void*)L.vals16 : (const void*)L.vals32;
+            const float* sc16 = fmt_rr == 2 ? L.scale16 : nullptr;
+#define SNS_RR(F, M)                                                                                                            \
+    hipLaunchKernelGGL((k_resid_restrict<F, M, 0>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, GhostSrc(), AgPut())
+            if (l == 0) time_begin(h, SPMV_B_MINUS_AX);                      // (bench.py's per-launch accounting of the fine-level passes)
+            if (fmt_rr == 2) { if (mode == 2) SNS_RR(2, 2); else if (mode == 1) SNS_RR(2, 1); else SNS_RR(2, 0); }
+            else             { if (mode == 2) SNS_RR(1, 2); else if (mode == 1) SNS_RR(1, 1); else SNS_RR(1, 0); }
+            if (l == 0) time_end(h);
+#undef SNS_RR
+        } else if (fuse && block_active(h, l + 1)) {
+            const int32_t ns = 8 * C.n_blk;
+            if (C.binv_fmt == 2)
+                hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+            else
+                hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+        } else {
+            hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
+                               C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
+        }
+    }
+    SNS_TRY(coarse_cycle(h, l + 1, cb, rep_src ? nullptr : C.x));
+    int s_first = 0;
+    // Fused coarse-grid correction + first post-smoothing sweep (k_post_lp): z = (cur + P xc) + om Dinv (r - M xc) with
+    // M = A P and r the residual restricted above -- the sweep reads M (0.37x the blocks of A on the fine level) instead
+    // of A and the prolongation kernel disappears.  Serial levels always; a distributed fine level when its single
+    // post-sweep is the exact global one (px): the ghost aggregates' corrections arrive by ONE level-(l+1) exchange
+    // instead of the level-l halo of the corrected iterate.
+    const int fmt_l = lp_format(h, L);
+    const bool fused_post = level_fused_post(h, l);
+    if (fused_post) {
+        const double* xc = cx;
+        if (L.xg) {                                    // distributed fine level: xc incl. the neighbours' aggregates
+            if (C.n_owned > 0)
+                HIP_TRY(hipMemcpyAsync(C.xg, cx, 4 * (size_t)C.n_owned * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            SNS_TRY(exchange_level(h, l + 1, C.xg));
+            xc = C.xg;
+        }
+        if (rows > 0) {
+            const int grid = (rows + 63) / 64;
+            const bool fine = (l == 0);
+            if (fine) time_begin(h, 4);
+            if (block_active(h, l) && L.binv32) {
+                const int32_t ns = 8 * L.n_blk;
+                const unsigned gb = (unsigned)((ns + 63) / 64);
+                if (fmt_l == 2)
+                    hipLaunchKernelGGL((k_bpost<2, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals16, L.ap_scale16, (const void*)L.binv32, xc, xc, (const double*)cur,
+                                       (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
+                else
+                    hipLaunchKernelGGL((k_bpost<1, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, (const void*)L.binv32, xc, xc,
+                                       (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
+            } else if (fmt_l == 2) {
+                if (fine)
+                    hipLaunchKernelGGL((k_post_lp<2, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth, GhostSrc());
+                else
+                    hipLaunchKernelGGL((k_post_lp<2, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       L.ap_vals16, L.ap_scale16, xc, cur, L.r, L.dinv32, om, L.agg, L.free_mask, oth, GhostSrc());
+            } else {
+                if (fine)
+                    hipLaunchKernelGGL((k_post_lp<1, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
+                                       L.free_mask, oth, GhostSrc());
+                else
+                    hipLaunchKernelGGL((k_post_lp<1, 0>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
+                                       (const void*)L.ap_vals32, (const float*)nullptr, xc, cur, L.r, L.dinv32, om, L.agg,
+                                       L.free_mask, oth, GhostSrc());
+            }
+            if (fine) time_end(h);
+        }
+        std::swap(cur, oth);
+        s_first = 1;
+    } else if (rows > 0) {
+        hipLaunchKernelGGL(k_prolong_add, dim3(g4), dim3(256), 0, h->stream, rows, L.agg, L.free_mask, cx, cur);
+    }
+    if (fused_post) {
+        // (the post-sweep is done; a partitioned fine level got its neighbours' corrections through xc)
+    } else if (px && l == 0 && nu == 1) {
+        // the single post-smoothing sweep of the fine level with the neighbours' corrected iterate: halo of `cur`
+        // overlapped with the interior rows of the sweep
+        SNS_TRY(exchange_and_spmv<SPMV_JACOBI>(h, cur, cur, oth, b, om, nullptr, true));
+        std::swap(cur, oth);
+        s_first = 1;
+    } else if (px) {
+        SNS_TRY(exchange_level(h, l, cur));
+        if (ghost4 > 0 && nu > 1)
+            HIP_TRY(hipMemcpyAsync(oth + 4 * (size_t)rows, cur + 4 * (size_t)rows, ghost4 * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    }
+    for (int s = s_first; s < nu_post; ++s) {
+        if (sx) SNS_TRY(exchange_level(h, l, cur));
+        launch_sweep(h, l, L, rows, cur, oth, b, om);
+        std::swap(cur, oth);
+    }
+    // cur == x by construction of the start buffer
+    return SNS_OK;
+}
+
+
+static int pc_apply_inner(sns_ctx* h, const double* r, double* z);
+// (first_sweep_done is consumed by the cycle this call runs and by nothing else: cleared on every way out)
+int pc_apply(sns_ctx* h, const double* r, double* z) {
+    const int rc = pc_apply_inner(h, r, z);
+    h->first_sweep_done = false;
+    return rc;
+}
+
+static int pc_apply_inner(sns_ctx* h, const double* r, double* z) {
+    const int64_t nd = nred_of(h);
+    switch (h->opt.pc_type) {
+        case SNS_PC_NONE:
+            HIP_TRY(hipMemcpyAsync(z, r, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            return SNS_OK;
+        case SNS_PC_BJACOBI:
+            hipLaunchKernelGGL(k_bjacobi, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, h->stream, h->n_owned,
+                               h->levels[0].dinv, r, 1.0, z);
+            return SNS_OK;
+        case SNS_PC_AMG:
+            if (h->n > h->n_owned) {
+                // distributed: the per-rank V-cycle must see ZERO ghost values on level 0 (block-Jacobi across
+                // ranks, like PETSc's parallel default bjacobi).  z's ghost tail may hold halo data, so cycle
+                // in internal buffers whose tails are never written and copy the owned part out.
+                // (fine_tails_unused: nothing in the fine level's cycle reads a ghost tail as zero -- no internal buffer, no copy)
+                if (fine_tails_unused(h)) return vcycle(h, 0, r, z);
+                SNS_TRY(vcycle(h, 0, r, h->levels[0].x));
+                HIP_TRY(hipMemcpyAsync(z, h->levels[0].x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                return SNS_OK;
+            }
+            return vcycle(h, 0, r, z);
+    }
+    set_error("bad pc_type");
+    return SNS_E_ARG;
+}
+
+
+// operator apply with halo exchange (x must have room for the ghost tail)
+int op_apply(sns_ctx* h, double* x, double* y) {
+    SNS_TRY(exchange_and_spmv<SPMV_AX>(h, x, x, y, nullptr, 0.0, nullptr, false));
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+
+// y = A x with the per-workgroup partial sums of <dotw, y> left in h->partial (BiCGStab's <rhat, A M p>)
+int op_apply_dot(sns_ctx* h, double* x, double* y, const double* dotw) {
+    SNS_TRY(exchange_and_spmv<SPMV_AX_DOT>(h, x, x, y, nullptr, 0.0, dotw, false));
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+
+int op_residual(sns_ctx* h, double* x, const double* b, double* r) {
+    SNS_TRY(exchange_and_spmv<SPMV_B_MINUS_AX>(h, x, x, r, b, 0.0, nullptr, false));
+    h->tm.spmv_calls++;
+    return SNS_OK;
+}
+
+
+}  // namespace sns

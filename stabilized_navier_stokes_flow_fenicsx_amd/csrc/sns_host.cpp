@@ -13,6 +13,7 @@
 #include <stdexcept>
 
 #include "sns_internal.h"
+#include "sns_policy.h"
 
 namespace sns {
 
@@ -483,5 +484,27 @@ extern "C" int sns_host_hessenberg_eigs(int n, const double* H, double* re, doub
         for (int i = lo; i <= hi; ++i) at(i, i) += mu;
     }
     for (int i = 0; i < n; ++i) { re[i] = ev[(size_t)i].real(); im[i] = ev[(size_t)i].imag(); }
+    return SNS_OK;
+}
+
+// the hierarchy's policy table on its own (csrc/sns_policy.h: the one place that holds the thresholds and schedules)
+extern "C" int sns_host_cycle_policy(const sns_options* opt, int nranks, int windows, int nlevels, const int64_t* rows_global,
+                                     int rep_level, int64_t rows_global_l1, const uint8_t* has_blocks, int32_t* kind,
+                                     int32_t* nu_pre, int32_t* nu_post, int32_t* exact) {
+    if (!opt || nranks < 1 || nlevels < 1 || nlevels > 16 || !rows_global || !kind || !nu_pre || !nu_post || rep_level < 0 ||
+        rep_level >= nlevels || rep_level == 1) {
+        sns::set_error("sns_host_cycle_policy: bad arguments (1..16 levels, rep_level 0 or in [2, nlevels))");
+        return SNS_E_ARG;
+    }
+    bool hb[16];
+    for (int l = 0; l < nlevels; ++l) hb[l] = has_blocks ? has_blocks[l] != 0 : true;
+    sns::policy::LevelRow rows[16];
+    sns::policy::cycle_table(*opt, nranks, windows != 0, nlevels, rows_global, rep_level, rows_global_l1, hb, rows);
+    for (int l = 0; l < nlevels; ++l) {
+        kind[l] = rows[l].cycled ? rows[l].kind : -1;
+        nu_pre[l] = rows[l].pre;
+        nu_post[l] = rows[l].post;
+        if (exact) exact[l] = rows[l].exact;
+    }
     return SNS_OK;
 }

@@ -156,7 +156,10 @@ template <int FMT, int MODE, int GH = 0>
 __global__ void k_resid_restrict(int32_t nc, int32_t n_cslots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                  const uint8_t* free_mask, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                                  const double* x, const double* b, double* r_out, double* bc, const float* dinv32_c, const void* binv_c,
-                                 double omega_c, double* z_c, GhostSrc gs);
+                                 double omega_c, double* z_c, GhostSrc gs, AgPut agp);
+template <int FMT>
+__global__ void k_bfirst_gather(int32_t n_slots, const int32_t* blk_rows, const void* binv, double omega, double* z, double* b_out,
+                                const int32_t* rowmap, AgGet ag);
 template <int FMT>
 __global__ void k_binv(int32_t nblk, const int32_t* blk_rows, const int32_t* blk_of, const int32_t* rowptr, const int32_t* colind,
                        const double* vals, void* binv, int* singular);

@@ -57,6 +57,29 @@ struct GhostSrc {
     long long timeout_ticks = 0;
 };
 
+// The two halves of an all-gather carried by solver kernels (the right-hand side of a partitioned run's replicated tail): the
+// kernel that PRODUCES a rank's piece stores it into every rank's staging area and raises the flags (AgPut), the kernel that
+// CONSUMES the gathered vector waits for every rank's flag and reads the pieces from its own staging area (AgGet) -- no
+// all-gather launch of its own.  Same staging areas, flags and round counter as the stand-alone all-gather (sns_comm.hip).
+struct AgPut {
+    double* const* ag = nullptr;                 // device array [nranks]: the ranks' staging areas (nullptr: off)
+    PeerCtl* const* ctl = nullptr;
+    const unsigned long long* seq = nullptr;     // round = *seq + 1 (stored by the consumer)
+    unsigned int* done = nullptr;
+    int rank = 0, nranks = 1, flags = 0;         // flags 0 (team transport): the host barrier orders the halves
+    long long stage_doubles = 0, slot_doubles = 0;
+};
+struct AgGet {
+    const double* stage = nullptr;               // this rank's staging area (nullptr: off)
+    const PeerCtl* ctl = nullptr;                // this rank's control area
+    unsigned long long* seq = nullptr;
+    unsigned int* done = nullptr;
+    int nranks = 1, flags = 0;
+    long long stage_doubles = 0;
+    int* err = nullptr;
+    long long timeout_ticks = 0;
+};
+
 __device__ __forceinline__ void peer_flag_store(unsigned long long* f, unsigned long long v) {
     __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -703,3 +703,43 @@ def test_bodyfitted_nozzle_channel_geometry(name):
     from stabilized_navier_stokes_flow_fenicsx_amd import drivers as D
     msh, _ = D.channel_problem_inputs(os.path.join(ROOT, "tests", "golden", name), 0.4, 0.2 if name.startswith("inlet_Tri") else 0.15)
     assert msh.meta["kind"] == "channel-nozzle"
+
+
+def test_hierarchy_policy_table(built_lib):
+    """the size thresholds and sweep schedules of the AMG hierarchy live in ONE host function
+    (csrc/sns_policy.h, exported as sns_host_cycle_policy) -- here its table for the hierarchies on record:
+    (kind, sweeps before, sweeps after the coarse-grid correction) per level; kind 0 nodal / 1 aggregate blocks / 2 one-workgroup
+    inverse / 3 blocked Gauss-Jordan inverse / 4 sweeps only / -1 the source of the replicated copy."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    T = lambda rows, **kw: [(r["kind"], r["pre"], r["post"]) for r in _lib.host_cycle_policy(rows, **kw)]
+    # the 10.1 M-tet duct on one GPU (profiles/r4_strong_rehearsal_team.txt, N = 1): nodal fine level, level 1 at 1 + 3 block
+    # sweeps, level 2 at 4 + 4, level 3 at 2 + 2, the 475-row level solved by the blocked inverse
+    serial = [1738576, 218044, 27436, 3800, 475]
+    assert T(serial) == [(0, 1, 1), (1, 1, 3), (1, 4, 4), (1, 2, 2), (3, 0, 0)]
+    # its 8-way strong split over RCCL (rank-local sweeps): blocks on the fine level too (217 k rows per rank <= 600 k), level 1 at
+    # 4 + 4, level 2 only the source of the replicated tail, which runs 4 + 4 / 2 + 2 / 2 + 2 and ends in the 136-row inverse
+    part = [1738576, 218044, 28880, 30027, 4454, 721, 136]
+    rccl = T(part, nranks=8, rep_level=3, rows_global_l1=218044)
+    assert rccl == [(1, 1, 1), (1, 4, 4), (-1, 0, 0), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
+    # ... over a window transport with amg_exact_sweeps (round 5): level 1 runs the single-GPU schedule with exact sweeps
+    win = _lib.host_cycle_policy(part, nranks=8, windows=True, rep_level=3, rows_global_l1=218044)
+    assert [(r["kind"], r["pre"], r["post"]) for r in win] == [(1, 1, 1), (1, 1, 3), (-1, 0, 0), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
+    assert [r["exact"] for r in win] == [0, 1, 0, 0, 0, 0, 0]
+    assert T(part, nranks=8, windows=True, rep_level=3, rows_global_l1=218044, amg_exact_sweeps=0) == rccl
+    # 2 ranks: 869 k rows per rank keep the nodal fine level
+    assert T([1738576, 218044, 27436, 29470, 4193, 597, 110], nranks=2, rep_level=3, rows_global_l1=218044)[0] == (0, 1, 1)
+    # large problems get more sweeps below level 1 (amg_nu_scale_with_size): 81 M tets (13.9 M rows): + (4, 6), halved for blocks
+    big = [13900000, 1740000, 218000, 27400, 3800, 475]
+    assert T(big) == [(0, 1, 1), (1, 1, 3), (1, 6, 6), (1, 5, 5), (1, 5, 5), (3, 0, 0)]
+    assert T(big, amg_nu_scale_with_size=0) == [(0, 1, 1), (1, 1, 3), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
+    # an unstructured mesh (first coarsening keeps more than one row in six) with a deep hierarchy enters the first tier early
+    unstr = [850748, 186650, 29289, 4726, 779, 136]
+    assert T(unstr)[2] == (1, 5, 5) and T(unstr, amg_nu_scale_with_size=0)[2] == (1, 4, 4)
+    # rounds 1-3's nodal-block cycle on request: level 1 at 1 + 6, level 2 at 6 + 6, deeper 2 + 2, down to the small inverse
+    old = [1738576, 218044, 27436, 3800, 475, 60, 8]
+    assert T(old, amg_block_smooth=0, amg_dense_rows=0) == [(0, 1, 1), (0, 1, 6), (0, 6, 6), (0, 2, 2), (0, 2, 2), (0, 2, 2), (2, 0, 0)]
+    # a last level too large for any inverse is swept; fixed level-1 counts win over the automatic ones
+    assert T([100000, 12500, 5000], amg_dense_rows=512)[-1] == (4, 0, 0)
+    assert T(serial, amg_nu_l1_pre=2, amg_nu_l1_post=2)[1] == (1, 2, 2)
+    # aggregate blocks only where the level is small enough per rank, when limited (amg_block_max_rows)
+    assert T(serial, amg_block_max_rows=8192) == [(0, 1, 1), (0, 1, 6), (0, 6, 6), (1, 2, 2), (3, 0, 0)]
