@@ -182,8 +182,11 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                 const void* __restrict__ vals_v, const float* __restrict__ scale,
                                                 const void* __restrict__ binv, const double* __restrict__ x,
-                                                double* __restrict__ y, const double* __restrict__ bvec, double omega, GhostSrc gs) {
+                                                double* __restrict__ y, const double* __restrict__ bvec, double omega, GhostSrc gs,
+                                                PutDst pd) {
     __shared__ double sres[8 * 32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     GhostReader gr;
     if (GH) gr.begin(gs);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
@@ -202,11 +205,17 @@ __global__ __launch_bounds__(256) void k_bsweep(int32_t n_slots, const int32_t* 
     }
     const double acc = sc * lp_row_times_x<FMT, GH>(s, e, colind, vals_v, x, r, &gr, &gs);
     const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
-    if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
+    bool stored = false;
+    if (live) {
+        const double val = pre_x + omega * z;
+        y[4 * (int64_t)row + r] = val;
+        if (pd.sr_ptr) stored = put_store(pd, pseq, row, r, val);
+    }
+    if (pd.sr_ptr) put_finish(pd, pseq, stored, &s_last, 0);
 }
 #define SNS_INST_BSWEEP(F, G)                                                                                                 \
     template __global__ void k_bsweep<F, G>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*, \
-                                            const void*, const double*, double*, const double*, double, GhostSrc);
+                                            const void*, const double*, double*, const double*, double, GhostSrc, PutDst);
 SNS_INST_BSWEEP(1, 0) SNS_INST_BSWEEP(2, 0) SNS_INST_BSWEEP(1, 1) SNS_INST_BSWEEP(2, 1)
 #undef SNS_INST_BSWEEP
 
@@ -222,8 +231,10 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
                                                const double* __restrict__ xc_own,
                                                const double* __restrict__ x_pre, const double* __restrict__ res1, double omega,
                                                const int32_t* __restrict__ agg, const uint8_t* __restrict__ free_mask,
-                                               double* __restrict__ y, GhostSrc gs) {
+                                               double* __restrict__ y, GhostSrc gs, PutDst pd) {
     __shared__ double sres[8 * 32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     GhostReader gr;
     if (GH) gr.begin(gs);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
@@ -244,12 +255,18 @@ __global__ __launch_bounds__(256) void k_bpost(int32_t n_slots, const int32_t* _
     }
     const double acc = sc * lp_row_times_x<FMT, GH>(s, e, colind, vals_v, xc, r, &gr, &gs);
     const double z = block_apply(Bv, live ? pre_b - acc : 0.0, sres + 32 * (tid >> 5), j);
-    if (live) y[4 * (int64_t)row + r] = pre_x + omega * z;
+    bool stored = false;
+    if (live) {
+        const double val = pre_x + omega * z;
+        y[4 * (int64_t)row + r] = val;
+        if (pd.sr_ptr) stored = put_store(pd, pseq, row, r, val);
+    }
+    if (pd.sr_ptr) put_finish(pd, pseq, stored, &s_last, 0);
 }
 #define SNS_INST_BPOST(F, G)                                                                                                  \
     template __global__ void k_bpost<F, G>(int32_t, const int32_t*, const int32_t*, const int32_t*, const void*, const float*, \
                                            const void*, const double*, const double*, const double*, const double*, double,   \
-                                           const int32_t*, const uint8_t*, double*, GhostSrc);
+                                           const int32_t*, const uint8_t*, double*, GhostSrc, PutDst);
 SNS_INST_BPOST(1, 0) SNS_INST_BPOST(2, 0) SNS_INST_BPOST(1, 1) SNS_INST_BPOST(2, 1)
 #undef SNS_INST_BPOST
 
@@ -257,8 +274,10 @@ SNS_INST_BPOST(1, 0) SNS_INST_BPOST(2, 0) SNS_INST_BPOST(1, 1) SNS_INST_BPOST(2,
 template <int FMT>
 __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* __restrict__ blk_rows,
                                                 const void* __restrict__ binv, const double* __restrict__ bvec, double omega,
-                                                double* __restrict__ z) {
+                                                double* __restrict__ z, PutDst pd) {
     __shared__ double sres[8 * 32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 3, j = lane & 31;
     const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
@@ -267,10 +286,15 @@ __global__ __launch_bounds__(256) void k_bfirst(int32_t n_slots, const int32_t* 
     BinvRow<FMT> Bv;
     Bv.load(binv, slot >> 3, j, in);
     const double zz = block_apply(Bv, live ? bvec[4 * (int64_t)row + r] : 0.0, sres + 32 * (tid >> 5), j);
-    if (live) z[4 * (int64_t)row + r] = omega * zz;
+    bool stored = false;
+    if (live) {
+        z[4 * (int64_t)row + r] = omega * zz;
+        if (pd.sr_ptr) stored = put_store(pd, pseq, row, r, omega * zz);
+    }
+    if (pd.sr_ptr) put_finish(pd, pseq, stored, &s_last, 0);
 }
-template __global__ void k_bfirst<1>(int32_t, const int32_t*, const void*, const double*, double, double*);
-template __global__ void k_bfirst<2>(int32_t, const int32_t*, const void*, const double*, double, double*);
+template __global__ void k_bfirst<1>(int32_t, const int32_t*, const void*, const double*, double, double*, PutDst);
+template __global__ void k_bfirst<2>(int32_t, const int32_t*, const void*, const double*, double, double*, PutDst);
 
 // First sweep of the REPLICATED tail's first level with the wait half of the all-gather of its right-hand side inside: row g of the
 // level is piece rowmap[g] (= rank * maxn + i) of the gathered vector, read from this rank's staging area once every rank's flag
@@ -326,8 +350,10 @@ __global__ __launch_bounds__(256) void k_bfirst_bicg(int32_t n_slots, const int3
                                                      const double* __restrict__ sc, const double* ph, const double* sh,
                                                      const double* __restrict__ t,
                                                      const double* __restrict__ v, double* __restrict__ x, double* __restrict__ r,
-                                                     double* __restrict__ p, double* __restrict__ s) {
+                                                     double* __restrict__ p, double* __restrict__ s, PutDst pd) {
     __shared__ double sres[8 * 32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
     const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
@@ -351,12 +377,17 @@ __global__ __launch_bounds__(256) void k_bfirst_bicg(int32_t n_slots, const int3
         }
     }
     const double zz = block_apply(Bv, val, sres + 32 * (tid >> 5), j);
-    if (live) z[4 * (int64_t)row + c] = omega_pc * zz;
+    bool stored = false;
+    if (live) {
+        z[4 * (int64_t)row + c] = omega_pc * zz;
+        if (pd.sr_ptr) stored = put_store(pd, pseq, row, c, omega_pc * zz);
+    }
+    if (pd.sr_ptr) put_finish(pd, pseq, stored, &s_last, 0);
 }
 #define SNS_INST_BFB(F, O)                                                                                                  \
     template __global__ void k_bfirst_bicg<F, O>(int32_t, const int32_t*, const void*, double, double*, const double*,         \
                                                  const double*, const double*, const double*, const double*, double*, double*, \
-                                                 double*, double*);
+                                                 double*, double*, PutDst);
 SNS_INST_BFB(1, 1) SNS_INST_BFB(1, 2) SNS_INST_BFB(2, 1) SNS_INST_BFB(2, 2)
 #undef SNS_INST_BFB
 
@@ -369,8 +400,10 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
                                                       const int32_t* __restrict__ m_ptr, const int32_t* __restrict__ m_idx,
                                                       const uint8_t* __restrict__ free_mask, const double* __restrict__ r,
                                                       double* __restrict__ bc, const void* __restrict__ binv_c, double omega_c,
-                                                      double* __restrict__ z_c) {
+                                                      double* __restrict__ z_c, PutDst pd) {
     __shared__ double sres[8 * 32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 3, j = lane & 31;
     const int32_t slot = ((int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x) * 4 + (tid >> 6)) * 16 + (lane >> 2);
     const bool in = slot < n_slots;
@@ -397,12 +430,17 @@ __global__ __launch_bounds__(256) void k_restrict_blk(int32_t n_slots, const int
         bc[4 * (int64_t)I + c] = s;
     }
     const double zz = block_apply(Bv, live ? s : 0.0, sres + 32 * (tid >> 5), j);
-    if (live) z_c[4 * (int64_t)I + c] = omega_c * zz;
+    bool stored = false;
+    if (live) {
+        z_c[4 * (int64_t)I + c] = omega_c * zz;
+        if (pd.sr_ptr) stored = put_store(pd, pseq, I, c, omega_c * zz);       // (the coarse level's plan: its first sweep is put at once)
+    }
+    if (pd.sr_ptr) put_finish(pd, pseq, stored, &s_last, 0);
 }
 template __global__ void k_restrict_blk<1>(int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, const double*,
-                                           double*, const void*, double, double*);
+                                           double*, const void*, double, double*, PutDst);
 template __global__ void k_restrict_blk<2>(int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, const double*,
-                                           double*, const void*, double, double*);
+                                           double*, const void*, double, double*, PutDst);
 
 // Residual + restriction (+ the coarse level's first sweep) of a level >= 1 in ONE launch:
 //     r = b - A x,      bc[I] = sum_{i in I} free_i r[i],      z_c = w_c S_c bc   (MODE 0: none, 1: nodal D_c^-1, 2: aggregate blocks B_c^-1)
@@ -421,13 +459,16 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
                                                         const double* __restrict__ bvec, double* __restrict__ r_out,
                                                         double* __restrict__ bc, const float* __restrict__ dinv32_c,
                                                         const void* __restrict__ binv_c, double omega_c, double* __restrict__ z_c,
-                                                        GhostSrc gs, AgPut agp) {
+                                                        GhostSrc gs, AgPut agp, PutDst pd) {
     __shared__ double sred[8][8][4];
     __shared__ double sbc[32];
+    __shared__ int s_last;
+    const unsigned long long pseq = put_begin(pd);
     GhostReader gr;
     if (GH) gr.begin(gs);
     // (agp: the restricted right-hand side also goes into every rank's all-gather staging area -- the level below is the source
     // of a partitioned run's replicated tail -- and the last workgroup raises this rank's flag there)
+    bool pstored = false;
     const unsigned long long ag_seq = agp.ag ? __hip_atomic_load(agp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull : 0ull;
     const int tid = threadIdx.x, hw = tid >> 5, q = (tid & 31) >> 2, c = tid & 3;
     const int32_t G = (int32_t)xcd_remap_b((int)blockIdx.x, (int)gridDim.x);          // the coarse smoother block of this workgroup
@@ -493,15 +534,19 @@ __global__ __launch_bounds__(256) void k_resid_restrict(int32_t nc, int32_t n_cs
             const int j = tid & 31;
             const double zz = Bv.dot(sbc);
             const int32_t J = (G * 8 + (j >> 2) < n_cslots) ? blk_rows_c[(int64_t)G * 8 + (j >> 2)] : -1;
-            if (J >= 0) z_c[4 * (int64_t)J + (j & 3)] = omega_c * zz;
+            if (J >= 0) {
+                z_c[4 * (int64_t)J + (j & 3)] = omega_c * zz;
+                if (pd.sr_ptr) pstored = put_store(pd, pseq, J, j & 3, omega_c * zz);
+            }
         }
     }
+    if (pd.sr_ptr) put_finish(pd, pseq, pstored, &s_last, 1);
 }
 #define SNS_INST_RR(F, M, G)                                                                                                        \
     template __global__ void k_resid_restrict<F, M, G>(int32_t, int32_t, const int32_t*, const int32_t*, const int32_t*, const uint8_t*, \
                                                        const int32_t*, const int32_t*, const void*, const float*, const double*,    \
                                                        const double*, double*, double*, const float*, const void*, double, double*, \
-                                                       GhostSrc, AgPut);
+                                                       GhostSrc, AgPut, PutDst);
 SNS_INST_RR(1, 0, 0) SNS_INST_RR(1, 1, 0) SNS_INST_RR(1, 2, 0) SNS_INST_RR(2, 0, 0) SNS_INST_RR(2, 1, 0) SNS_INST_RR(2, 2, 0)
 SNS_INST_RR(1, 0, 1) SNS_INST_RR(1, 1, 1) SNS_INST_RR(1, 2, 1) SNS_INST_RR(2, 0, 1) SNS_INST_RR(2, 1, 1) SNS_INST_RR(2, 2, 1)
 #undef SNS_INST_RR

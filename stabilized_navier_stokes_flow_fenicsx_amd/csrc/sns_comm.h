@@ -70,6 +70,12 @@ struct Plan {                                    // halo plan of one level (coun
     unsigned long long* win_flag = nullptr;
     unsigned long long* d_seq = nullptr;         // device word: rounds put so far (k_halo_put advances it)
     int32_t *d_send_ptr = nullptr;
+    int32_t *d_sr_ptr = nullptr, *d_sr_dst = nullptr;   // per owned row: its send entries, neighbour k << 27 | slot (PutDst)
+    int32_t n_sent_rows = 0;                     // owned rows with at least one send entry
+    unsigned int* d_expect = nullptr;            // PutDst::expect (comm_plan_put_groups) for the block slots expect_key / expect_slots
+    unsigned int h_expect[2] = {0, 0};
+    const int32_t* expect_key = nullptr;
+    int32_t expect_slots = 0;
     double** d_put = nullptr;                    // [2][nn] remote payload addresses
     unsigned long long** d_rflag = nullptr;      // [nn] remote flag addresses
     unsigned int* d_done = nullptr;
@@ -111,6 +117,12 @@ int comm_exchange(Comm* c, const Plan& p, double* x, hipStream_t s);
 // ghost entries from the window.  team: returns after the host barrier (every rank's put has completed).
 int comm_put(Comm* c, const Plan& p, const double* x, hipStream_t s);
 GhostSrc comm_ghost_src(const Comm* c, const Plan& p);
+// the put carried by the kernel that produces the vector: pass comm_put_dst to that kernel, then comm_put_carried (the team's
+// host barrier, the peer's error check) in place of comm_put.  A plan that cannot carry it answers with an empty PutDst: the
+// caller falls back to comm_put.
+int comm_plan_put_groups(Comm* c, Plan& p, const int32_t* blk_rows, int32_t n_slots, hipStream_t s);   // (setup; enables comm_put_dst)
+PutDst comm_put_dst(const Comm* c, const Plan& p);
+int comm_put_carried(Comm* c, const Plan& p, hipStream_t s);
 int comm_allreduce_sum(Comm* c, double* buf_dev, int count, hipStream_t s);
 // every rank contributes `count` doubles; recv_dev gets nranks*count (rank order)
 int comm_allgather(Comm* c, const double* send_dev, double* recv_dev, int count, hipStream_t s);

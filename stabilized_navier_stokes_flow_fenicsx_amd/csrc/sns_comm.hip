@@ -217,6 +217,12 @@ void plan_free(Plan& p) {
     if (p.send_buf) (void)hipFree(p.send_buf);
     if (p.recv_buf) (void)hipFree(p.recv_buf);
     if (p.d_send_ptr) (void)hipFree(p.d_send_ptr);
+    if (p.d_sr_ptr) (void)hipFree(p.d_sr_ptr);
+    if (p.d_sr_dst) (void)hipFree(p.d_sr_dst);
+    p.d_sr_ptr = p.d_sr_dst = nullptr;
+    if (p.d_expect) (void)hipFree(p.d_expect);
+    p.d_expect = nullptr;
+    p.expect_key = nullptr;
     if (p.d_put) (void)hipFree(p.d_put);
     if (p.d_rflag) (void)hipFree(p.d_rflag);
     if (p.d_done) (void)hipFree(p.d_done);
@@ -253,6 +259,73 @@ int comm_put(Comm* c, const Plan& p, const double* x, hipStream_t s) {
     const unsigned gp = (unsigned)std::max<int64_t>(1, (2 * (int64_t)ns + 255) / 256);
     hipLaunchKernelGGL(k_halo_put, dim3(gp), dim3(256), 0, s, ns, nn, p.send_idx, p.d_send_ptr, x, p.d_put,
                        c->peer->host_sync ? (unsigned long long* const*)nullptr : p.d_rflag, p.d_seq, p.d_done);
+    return comm_host_barrier(c, s);
+}
+
+// workgroups of a producing kernel that hold a sent row (PutDst::expect), for its two slot groupings; out[2]: sent rows covered
+__global__ void k_count_put_groups(int32_t ns, const int32_t* __restrict__ blk_rows, const int32_t* __restrict__ sr_ptr,
+                                   unsigned int* __restrict__ out) {
+    const int32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (8 * (int64_t)g >= ns) return;
+    unsigned int n8 = 0;
+    for (int32_t q = 8 * g; q < std::min(ns, 8 * g + 8); ++q) {
+        const int32_t row = blk_rows[q];
+        if (row >= 0 && sr_ptr[row + 1] > sr_ptr[row]) ++n8;
+    }
+    if (n8) {
+        atomicAdd(&out[1], 1u);
+        atomicAdd(&out[2], n8);
+    }
+    if (g % 8 == 0) {
+        bool any = false;
+        for (int32_t q = 8 * g; q < std::min(ns, 8 * g + 64) && !any; ++q) {
+            const int32_t row = blk_rows[q];
+            any = row >= 0 && sr_ptr[row + 1] > sr_ptr[row];
+        }
+        if (any) atomicAdd(&out[0], 1u);
+    }
+}
+
+// (setup, once per hierarchy: blk_rows = the level's block slots, 8 per aggregate block)
+int comm_plan_put_groups(Comm* c, Plan& p, const int32_t* blk_rows, int32_t n_slots, hipStream_t s) {
+    if (!c || !c->peer || !p.d_sr_ptr || p.nbr.empty()) return SNS_OK;
+    if (p.expect_key == blk_rows && p.expect_slots == n_slots) return SNS_OK;
+    p.expect_key = nullptr;
+    p.h_expect[0] = p.h_expect[1] = 0;
+    if (!blk_rows || n_slots <= 0) return SNS_OK;
+    if (!p.d_expect) CHIP(hipMalloc((void**)&p.d_expect, 3 * sizeof(unsigned int)));
+    CHIP(hipMemsetAsync(p.d_expect, 0, 3 * sizeof(unsigned int), s));
+    const int32_t ng = (n_slots + 7) / 8;
+    hipLaunchKernelGGL(k_count_put_groups, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, n_slots, blk_rows, p.d_sr_ptr, p.d_expect);
+    unsigned int e[3] = {0, 0, 0};
+    CHIP(hipMemcpyAsync(e, p.d_expect, sizeof(e), hipMemcpyDeviceToHost, s));
+    CHIP(hipStreamSynchronize(s));
+    if (e[2] != (unsigned int)p.n_sent_rows) return SNS_OK;      // (a sent row outside the blocks: the plan cannot carry its put)
+    p.h_expect[0] = e[0];
+    p.h_expect[1] = e[1];
+    p.expect_key = blk_rows;
+    p.expect_slots = n_slots;
+    return SNS_OK;
+}
+
+// ... the same put carried by the kernel that produces x (PutDst; off when the plan cannot: no neighbours, RCCL): the caller
+// launches that kernel and then calls comm_put_carried in place of comm_put
+PutDst comm_put_dst(const Comm* c, const Plan& p) {
+    PutDst d;
+    if (!c || !c->peer || p.nbr.empty() || !p.d_put || !p.d_sr_ptr || !p.expect_key || p.h_expect[0] == 0) return d;
+    d.expect = p.d_expect;
+    d.sr_ptr = p.d_sr_ptr;
+    d.sr_dst = p.d_sr_dst;
+    d.put = p.d_put;
+    d.rflag = c->peer->host_sync ? (unsigned long long* const*)nullptr : p.d_rflag;
+    d.seq = p.d_seq;
+    d.done = p.d_done;
+    d.nn = (int)p.nbr.size();
+    return d;
+}
+int comm_put_carried(Comm* c, const Plan& p, hipStream_t s) {
+    if (!c || !c->peer) { set_error("comm_put_carried: no window transport"); return SNS_E_STATE; }
+    if (!p.nbr.empty()) CTRY(peer_check(c));
     return comm_host_barrier(c, s);
 }
 
@@ -617,6 +690,31 @@ int peer_plan_connect(Comm* c, Plan& p, const PlanOffers& t) {
     if (sp.empty()) sp.assign(1, 0);
     CHIP(hipMalloc((void**)&p.d_send_ptr, sp.size() * sizeof(int32_t)));
     CHIP(hipMemcpy(p.d_send_ptr, sp.data(), sp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        // per owned row: where it is sent (the put carried by the producing kernel, comm_put_dst)
+        const int32_t no = std::max<int32_t>(p.n_own, 0);
+        std::vector<int32_t> rp((size_t)no + 1, 0), rd((size_t)std::max<int32_t>(1, p.n_send()), 0);
+        bool ok = nn < 16 && p.h_send_idx.size() >= (size_t)p.n_send();
+        for (int k = 0; k < nn && ok; ++k)
+            for (int32_t q = p.send_ptr[(size_t)k]; q < p.send_ptr[(size_t)k + 1]; ++q) {
+                const int32_t row = p.h_send_idx[(size_t)q];
+                if (row < 0 || row >= no || q - p.send_ptr[(size_t)k] >= (1 << 27)) { ok = false; break; }
+                ++rp[(size_t)row + 1];
+            }
+        if (ok) {
+            p.n_sent_rows = 0;
+            for (int32_t i = 0; i < no; ++i) p.n_sent_rows += rp[(size_t)i + 1] > 0 ? 1 : 0;
+            for (int32_t i = 0; i < no; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
+            std::vector<int32_t> at(rp.begin(), rp.end() - 1);
+            for (int k = 0; k < nn; ++k)
+                for (int32_t q = p.send_ptr[(size_t)k]; q < p.send_ptr[(size_t)k + 1]; ++q)
+                    rd[(size_t)at[(size_t)p.h_send_idx[(size_t)q]]++] = (int32_t)(((uint32_t)k << 27) | (uint32_t)(q - p.send_ptr[(size_t)k]));
+            CHIP(hipMalloc((void**)&p.d_sr_ptr, rp.size() * sizeof(int32_t)));
+            CHIP(hipMemcpy(p.d_sr_ptr, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CHIP(hipMalloc((void**)&p.d_sr_dst, rd.size() * sizeof(int32_t)));
+            CHIP(hipMemcpy(p.d_sr_dst, rd.data(), rd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
     CHIP(hipMalloc((void**)&p.d_put, put.size() * sizeof(double*)));
     CHIP(hipMalloc((void**)&p.d_rflag, rflag.size() * sizeof(unsigned long long*)));
     CHIP(hipMemcpy(p.d_put, put.data(), put.size() * sizeof(double*), hipMemcpyHostToDevice));

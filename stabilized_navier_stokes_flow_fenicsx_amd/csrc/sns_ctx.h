@@ -140,6 +140,14 @@ struct sns_ctx {
     bool team_overlap = false;                       // SNS_TEAM_OVERLAP: the team transport takes the two-stream path too (tests)
     double* arn_V = nullptr;                          // Arnoldi basis of the damping estimate, 9 vectors of the largest level >= ... asked for
     size_t arn_cap = 0;
+    // the put half of a halo exchange carried by the kernel that produced the vector (PutDst, round 5): first_put_carried -- the
+    // Krylov kernel that ran the fine level's first sweep put it too; child_put_carried -- the restriction put the next level's first
+    // sweep; put_pending -- the last kernel of a window cycle put its result (the vector named), the next exchange of exactly that
+    // vector is comm_put_carried; pc_then_op -- the caller of pc_apply promises that an operator application of the result follows
+    // (only then may the fine level's last kernel carry the put: a round nobody consumes would void the windows' flow control)
+    bool fuse_puts = std::getenv("SNS_NO_CARRIED_PUT") == nullptr;      // (A/B switch of the harnesses; not an option)
+    bool first_put_carried = false, child_put_carried = false, pc_then_op = false;
+    const double* put_pending = nullptr;
     bool first_sweep_done = false;                   // the V-cycle's fine-level first sweep was done by the Krylov kernel that wrote its input
     bool r3_estimates = false;                       // SNS_R3_SPECTRAL_ESTIMATE (tests of the retry path): round 3's policy -- spectral
                                                      // estimates every 4th setup whatever the operator (first Jacobians on the Stokes estimate)
@@ -501,7 +509,9 @@ int exchange_and_spmv(sns_ctx* h, double* xe, const double* x, double* y, const 
         // window transports: ONE put launch; the pass reads the ghost entries from the receive window and its boundary waves
         // wait for the neighbours' flags themselves -- no unpack, no boundary launch, no second stream
         ++h->ctr_exchange;
-        SNS_TRY(comm_put(c, c->plans[0], xe, h->stream));
+        if (h->put_pending == xe) SNS_TRY(comm_put_carried(c, c->plans[0], h->stream));    // (the cycle's last kernel put it)
+        else SNS_TRY(comm_put(c, c->plans[0], xe, h->stream));
+        h->put_pending = nullptr;
         Split s3;
         s3.mode = 3;
         s3.gs = comm_ghost_src(c, c->plans[0]);
@@ -583,27 +593,32 @@ inline void launch_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const 
         if (grid == 0) return;
         if (L.binv_fmt == 2)
             hipLaunchKernelGGL((k_bsweep<2, 0>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, GhostSrc());
+                               (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, GhostSrc(), PutDst());
         else
             hipLaunchKernelGGL((k_bsweep<1, 0>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                               (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, GhostSrc());
+                               (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, GhostSrc(), PutDst());
         return;
     }
     launch_pc_spmv<SPMV_JACOBI>(h, L, rows, x, y, b, omega);
 }
 
 // first sweep of a cycle from the zero guess, z = w S b (omega = 1: S b alone, the spectral estimate's operator)
-inline void launch_first_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double* b, double omega, double* z) {
+inline void launch_first_sweep(sns_ctx* h, int l, const Level& L, int32_t rows, const double* b, double omega, double* z,
+                               PutDst* pd = nullptr) {
     if (rows <= 0) return;
     const int g4 = (int)((4 * (int64_t)rows + 255) / 256);
     if (block_active(h, l) && L.binv32) {
         const int32_t ns = 8 * L.n_blk;
         if (L.binv_fmt == 2)
             hipLaunchKernelGGL((k_bfirst<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
-                               (const void*)L.binv32, b, omega, z);
+                               (const void*)L.binv32, b, omega, z, pd ? *pd : PutDst());
         else
             hipLaunchKernelGGL((k_bfirst<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, L.blk_rows,
-                               (const void*)L.binv32, b, omega, z);
+                               (const void*)L.binv32, b, omega, z, pd ? *pd : PutDst());
+        return;
+    }
+    if (pd) *pd = PutDst();                              // (the nodal first sweeps do not carry a put)
+    if (false) {
     } else if (lp_format(h, L) != 0 && L.dinv32) {
         hipLaunchKernelGGL(k_bjacobi32, dim3(g4), dim3(256), 0, h->stream, rows, L.dinv32, b, omega, z);
     } else {
@@ -761,16 +776,17 @@ inline int serial_graph_level(const sns_ctx* h) {
 
 
 // one aggregate-block sweep of a partitioned level with the ghost entries of x from the level's receive window
-inline void launch_sweep_windows(sns_ctx* h, const Level& L, const double* x, double* y, const double* b, double omega, const GhostSrc& gs) {
+inline void launch_sweep_windows(sns_ctx* h, const Level& L, const double* x, double* y, const double* b, double omega, const GhostSrc& gs,
+                                 const PutDst& pd = PutDst()) {
     const int32_t ns = 8 * L.n_blk;
     const unsigned grid = (unsigned)((ns + 63) / 64);
     if (grid == 0) return;
     if (L.binv_fmt == 2)
         hipLaunchKernelGGL((k_bsweep<2, 1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                           (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, gs);
+                           (const void*)L.vals16, L.scale16, (const void*)L.binv32, x, y, b, omega, gs, pd);
     else
         hipLaunchKernelGGL((k_bsweep<1, 1>), dim3(grid), dim3(256), 0, h->stream, ns, L.blk_rows, L.rowptr, L.colind,
-                           (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, gs);
+                           (const void*)L.vals32, (const float*)nullptr, (const void*)L.binv32, x, y, b, omega, gs, pd);
 }
 
 
@@ -797,6 +813,14 @@ inline bool level_windows(const sns_ctx* h, int l) {
                c->plans[1].win_recv[0] != nullptr;
     }
     return level_exact(h, l);
+}
+
+// the put of the fine level's first sweep when a Krylov kernel runs that sweep (k_bfirst_bicg): empty unless the fine level runs
+// the window form of the cycle
+inline PutDst first_sweep_put(const sns_ctx* h) {
+    const Comm* c = h->comm.get();
+    if (!h->fuse_puts || !c || !c->peer || !level_windows(h, 0)) return PutDst();
+    return comm_put_dst(c, c->plans[0]);
 }
 
 

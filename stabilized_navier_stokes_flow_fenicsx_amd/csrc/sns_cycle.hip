@@ -77,13 +77,31 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
     level_sweeps(h, l, nu_pre, nu_post);
     double* cur = cycle_start_buffer(h, l, x);
     double* oth = (cur == x) ? h->pong[l] : x;
-    if (rows > 0 && !(l > 0 && restrict_fuses_first(h, l - 1)) && !(l == 0 && h->first_sweep_done))
-        launch_first_sweep(h, l, L, rows, b, om, cur);
+    // The put of every exchange of this level's iterate rides in the kernel that PRODUCES the iterate (PutDst) where that is an
+    // aggregate-block kernel: `carried` says whether the vector about to be exchanged has been put already
+    const bool blk = block_active(h, l) && L.binv32 != nullptr;
+    const PutDst pdl = (h->fuse_puts && blk && rows > 0) ? comm_put_dst(c, P) : PutDst();
+    bool carried = false;
+    if (l == 0 && h->first_sweep_done) carried = h->first_put_carried;
+    else if (l > 0 && restrict_fuses_first(h, l - 1)) carried = h->child_put_carried;
+    else if (rows > 0) {
+        PutDst pd1 = pdl;
+        launch_first_sweep(h, l, L, rows, b, om, cur, &pd1);
+        carried = pd1.sr_ptr != nullptr;
+    }
+    h->first_put_carried = h->child_put_carried = false;
     if (l == 0) h->first_sweep_done = false;
-    for (int s = 1; s < nu_pre; ++s) {                     // (level >= 1 only: the fine level runs one sweep per half cycle)
+    auto put = [&](const Plan& Q, const double* v, bool was_carried) -> int {
         ++h->ctr_exchange;
-        SNS_TRY(comm_put(c, P, cur, h->stream));
-        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        return was_carried ? comm_put_carried(c, Q, h->stream) : comm_put(c, Q, v, h->stream);
+    };
+    for (int s = 1; s < nu_pre; ++s) {                     // (level >= 1 only: the fine level runs one sweep per half cycle)
+        SNS_TRY(put(P, cur, carried));
+        carried = false;
+        if (rows > 0 && blk) {
+            launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P), pdl);
+            carried = pdl.sr_ptr != nullptr;
+        }
         std::swap(cur, oth);
     }
     const bool rep_src = h->rep_level > 0 && l + 1 == h->rep_level - 1;
@@ -94,9 +112,14 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
     double* zc = fuse ? cycle_start_buffer(h, l + 1, C.x) : nullptr;
     const int fmt = lp_format(h, L);
     // residual (+ restriction): the true residual needs the neighbours' iterate
-    ++h->ctr_exchange;
-    SNS_TRY(comm_put(c, P, cur, h->stream));
+    SNS_TRY(put(P, cur, carried));
+    carried = false;
     const GhostSrc gs = comm_ghost_src(c, P);
+    // (the next level's first sweep, written by the restriction, is exchanged first thing in its cycle: put from here)
+    const PutDst pdc = (h->fuse_puts && fuse && block_active(h, l + 1) && !rep_src && level_windows(h, l + 1) && C.n_owned > 0 &&
+                        (l == 0 || rows > 0))
+                           ? comm_put_dst(c, c->plans[l + 1]) : PutDst();
+    h->child_put_carried = pdc.sr_ptr != nullptr;
     if (l == 0) {
         Split s3;
         s3.mode = 3;
@@ -107,10 +130,10 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
                 const int32_t ns = 8 * C.n_blk;
                 if (C.binv_fmt == 2)
                     hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc, pdc);
                 else
                     hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                                       L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc, pdc);
             } else {
                 hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
                                    C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
@@ -128,7 +151,7 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
         const float* sc16 = fmt == 2 ? L.scale16 : nullptr;
 #define SNS_RRW(F, M)                                                                                                              \
     hipLaunchKernelGGL((k_resid_restrict<F, M, 1>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
-                       L.free_mask, L.rowptr, L.colind, vals, sc16, (const double*)cur, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, gs, agp)
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, (const double*)cur, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, gs, agp, pdc)
         if (fmt == 2) { if (mode == 2) SNS_RRW(2, 2); else if (mode == 1) SNS_RRW(2, 1); else SNS_RRW(2, 0); }
         else          { if (mode == 2) SNS_RRW(1, 2); else if (mode == 1) SNS_RRW(1, 1); else SNS_RRW(1, 0); }
 #undef SNS_RRW
@@ -144,10 +167,13 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
         xc = h->levels[h->rep_level].x;
         apc = L.ap_colind_rep;
     } else {
-        ++h->ctr_exchange;
-        SNS_TRY(comm_put(c, c->plans[l + 1], cx, h->stream));
+        SNS_TRY(put(c->plans[l + 1], cx, h->put_pending == cx));       // (the level below put its result with its last kernel)
         gc = comm_ghost_src(c, c->plans[l + 1]);
     }
+    h->put_pending = nullptr;
+    // this level's result is exchanged next by the level above (its correction reads it) or, the fine level's, by the operator
+    // application the caller of pc_apply has promised: the last kernel of the cycle puts it
+    const bool last_puts = pdl.sr_ptr && (l == 0 ? h->pc_then_op : level_windows(h, l - 1));
     if (rows > 0) {
         if (l == 0) time_begin(h, 4);
         if (block_active(h, l) && L.binv32) {
@@ -157,7 +183,9 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
             const float* ms = fmt == 2 ? L.ap_scale16 : nullptr;
 #define SNS_BPW(F, G)                                                                                                          \
     hipLaunchKernelGGL((k_bpost<F, G>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, apc, mv, ms,             \
-                       (const void*)L.binv32, xc, cx, (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, gc)
+                       (const void*)L.binv32, xc, cx, (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, gc,                   \
+                       (nu_post > 1 || last_puts) ? pdl : PutDst())
+            carried = (nu_post > 1 || last_puts) && pdl.sr_ptr != nullptr;
             if (gc.win[0]) { if (fmt == 2) SNS_BPW(2, 1); else SNS_BPW(1, 1); }
             else           { if (fmt == 2) SNS_BPW(2, 0); else SNS_BPW(1, 0); }
 #undef SNS_BPW
@@ -175,12 +203,17 @@ int vcycle_windows(sns_ctx* h, int l, const double* b, double* x) {
     }
     std::swap(cur, oth);
     for (int s = 1; s < nu_post; ++s) {
-        ++h->ctr_exchange;
-        SNS_TRY(comm_put(c, P, cur, h->stream));
-        if (rows > 0) launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P));
+        SNS_TRY(put(P, cur, carried));
+        carried = false;
+        if (rows > 0 && blk) {
+            const bool more = s + 1 < nu_post || last_puts;
+            launch_sweep_windows(h, L, cur, oth, b, om, comm_ghost_src(c, P), more ? pdl : PutDst());
+            carried = more && pdl.sr_ptr != nullptr;
+        }
         std::swap(cur, oth);
     }
     // cur == x by construction of the start buffer
+    h->put_pending = carried ? cur : nullptr;
     return SNS_OK;
 }
 
@@ -340,7 +373,7 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             const float* sc16 = fmt_rr == 2 ? L.scale16 : nullptr;
 #define SNS_RR(F, M)                                                                                                            \
     hipLaunchKernelGGL((k_resid_restrict<F, M, 0>), dim3(grid), dim3(256), 0, h->stream, C.n_owned, n_slots, slots, L.m_ptr, L.m_idx, \
-                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, GhostSrc(), AgPut())
+                       L.free_mask, L.rowptr, L.colind, vals, sc16, xres, b, L.r, cb, dc, (const void*)C.binv32, C.omega, zc, GhostSrc(), AgPut(), PutDst())
             if (l == 0) time_begin(h, SPMV_B_MINUS_AX);                      // (bench.py's per-launch accounting of the fine-level passes)
             if (fmt_rr == 2) { if (mode == 2) SNS_RR(2, 2); else if (mode == 1) SNS_RR(2, 1); else SNS_RR(2, 0); }
             else             { if (mode == 2) SNS_RR(1, 2); else if (mode == 1) SNS_RR(1, 1); else SNS_RR(1, 0); }
@@ -350,10 +383,10 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
             const int32_t ns = 8 * C.n_blk;
             if (C.binv_fmt == 2)
                 hipLaunchKernelGGL((k_restrict_blk<2>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc, PutDst());
             else
                 hipLaunchKernelGGL((k_restrict_blk<1>), dim3((unsigned)((ns + 63) / 64)), dim3(256), 0, h->stream, ns, C.blk_rows,
-                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc);
+                                   L.m_ptr, L.m_idx, L.free_mask, L.r, cb, (const void*)C.binv32, C.omega, zc, PutDst());
         } else {
             hipLaunchKernelGGL(k_restrict, dim3((unsigned)((4 * (int64_t)C.n_owned + 255) / 256)), dim3(256), 0, h->stream,
                                C.n_owned, L.m_ptr, L.m_idx, L.free_mask, L.r, cb, dc, C.omega, zc);
@@ -386,11 +419,11 @@ int vcycle(sns_ctx* h, int l, const double* b, double* x) {
                 if (fmt_l == 2)
                     hipLaunchKernelGGL((k_bpost<2, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
                                        (const void*)L.ap_vals16, L.ap_scale16, (const void*)L.binv32, xc, xc, (const double*)cur,
-                                       (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
+                                       (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc(), PutDst());
                 else
                     hipLaunchKernelGGL((k_bpost<1, 0>), dim3(gb), dim3(256), 0, h->stream, ns, L.blk_rows, L.ap_rowptr, L.ap_colind,
                                        (const void*)L.ap_vals32, (const float*)nullptr, (const void*)L.binv32, xc, xc,
-                                       (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc());
+                                       (const double*)cur, (const double*)L.r, om, L.agg, L.free_mask, oth, GhostSrc(), PutDst());
             } else if (fmt_l == 2) {
                 if (fine)
                     hipLaunchKernelGGL((k_post_lp<2, 1>), dim3(grid), dim3(256), 0, h->stream, rows, L.ap_rowptr, L.ap_colind,
@@ -443,7 +476,8 @@ static int pc_apply_inner(sns_ctx* h, const double* r, double* z);
 // (first_sweep_done is consumed by the cycle this call runs and by nothing else: cleared on every way out)
 int pc_apply(sns_ctx* h, const double* r, double* z) {
     const int rc = pc_apply_inner(h, r, z);
-    h->first_sweep_done = false;
+    h->first_sweep_done = h->first_put_carried = h->child_put_carried = h->pc_then_op = false;
+    if (rc != SNS_OK || h->put_pending != z) h->put_pending = nullptr;
     return rc;
 }
 

@@ -138,25 +138,28 @@ inline size_t dense_gj_work_doubles(int Np) { return (size_t)4 * 64 * Np + 4 * 4
 template <int FMT, int GH = 0>
 __global__ void k_bsweep(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
                          const float* scale, const void* binv, const double* x, double* y, const double* bvec, double omega,
-                         GhostSrc gs);
+                         GhostSrc gs, PutDst pd);
 template <int FMT, int GH = 0>
 __global__ void k_bpost(int32_t n_slots, const int32_t* blk_rows, const int32_t* rowptr, const int32_t* colind, const void* vals,
                         const float* scale, const void* binv, const double* xc, const double* xc_own, const double* x_pre,
-                        const double* res1, double omega, const int32_t* agg, const uint8_t* free_mask, double* y, GhostSrc gs);
+                        const double* res1, double omega, const int32_t* agg, const uint8_t* free_mask, double* y, GhostSrc gs,
+                        PutDst pd);
 template <int FMT>
-__global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const void* binv, const double* bvec, double omega, double* z);
+__global__ void k_bfirst(int32_t n_slots, const int32_t* blk_rows, const void* binv, const double* bvec, double omega, double* z,
+                         PutDst pd);
 template <int FMT, int OP>
 __global__ void k_bfirst_bicg(int32_t n_slots, const int32_t* blk_rows, const void* binv, double omega_pc, double* z, const double* sc,
                               const double* ph, const double* sh, const double* t, const double* v, double* x, double* r, double* p,
-                              double* s);
+                              double* s, PutDst pd);
 template <int FMT>
 __global__ void k_restrict_blk(int32_t n_slots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
-                               const uint8_t* free_mask, const double* r, double* bc, const void* binv_c, double omega_c, double* z_c);
+                               const uint8_t* free_mask, const double* r, double* bc, const void* binv_c, double omega_c, double* z_c,
+                               PutDst pd);
 template <int FMT, int MODE, int GH = 0>
 __global__ void k_resid_restrict(int32_t nc, int32_t n_cslots, const int32_t* blk_rows_c, const int32_t* m_ptr, const int32_t* m_idx,
                                  const uint8_t* free_mask, const int32_t* rowptr, const int32_t* colind, const void* vals, const float* scale,
                                  const double* x, const double* b, double* r_out, double* bc, const float* dinv32_c, const void* binv_c,
-                                 double omega_c, double* z_c, GhostSrc gs, AgPut agp);
+                                 double omega_c, double* z_c, GhostSrc gs, AgPut agp, PutDst pd);
 template <int FMT>
 __global__ void k_bfirst_gather(int32_t n_slots, const int32_t* blk_rows, const void* binv, double omega, double* z, double* b_out,
                                 const int32_t* rowmap, AgGet ag);

@@ -85,6 +85,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
         HIP_TRY(hipMemsetAsync(v, 0, nd * sizeof(double), h->stream));
         auto first_half = [&](bool p_done) -> int {       // p, ph = M p, v = A ph, alpha
             if (!p_done) hipLaunchKernelGGL(k_bicg_p, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, p);
+            h->pc_then_op = true;
             SNS_TRY(pc_apply(h, p, ph));
             SNS_TRY(op_apply_dot(h, ph, v, rhat));        // v = A ph with the fused partial sums of <rhat, v>
             SNS_TRY(reduce_bicg<1>(h, h->dot_partials, red, sc));                  // alpha
@@ -100,14 +101,16 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
                 if (block_active(h, 0)) {
                     const int32_t ns = 8 * L0.n_blk;
                     const unsigned gb = (unsigned)((ns + 63) / 64);
+                    const PutDst pd0 = first_sweep_put(h);
+                    h->first_put_carried = pd0.sr_ptr != nullptr;
                     if (L0.binv_fmt == 2)
                         hipLaunchKernelGGL((k_bfirst_bicg<2, 1>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows, (const void*)L0.binv32,
                                            L0.omega, z1, sc, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, v,
-                                           (double*)nullptr, r, (double*)nullptr, s);
+                                           (double*)nullptr, r, (double*)nullptr, s, pd0);
                     else
                         hipLaunchKernelGGL((k_bfirst_bicg<1, 1>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows, (const void*)L0.binv32,
                                            L0.omega, z1, sc, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, v,
-                                           (double*)nullptr, r, (double*)nullptr, s);
+                                           (double*)nullptr, r, (double*)nullptr, s, pd0);
                 } else {
                     hipLaunchKernelGGL(k_bicg_s_first, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s, L0.dinv32, L0.omega, z1);
                 }
@@ -115,6 +118,7 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
             } else {
                 hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(256), 0, h->stream, nd, r, sc, v, s);
             }
+            h->pc_then_op = true;
             SNS_TRY(pc_apply(h, s, sh));
             SNS_TRY(op_apply(h, sh, t));
             hipLaunchKernelGGL(k_bicg_dots5, dim3(g), dim3(256), 0, h->stream, nd, s, t, rhat, h->partial);
@@ -130,14 +134,16 @@ int bicgstab(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_o
                     if (block_active(h, 0)) {
                         const int32_t ns = 8 * L0.n_blk;
                         const unsigned gb = (unsigned)((ns + 63) / 64);
+                        const PutDst pd0 = first_sweep_put(h);
+                        h->first_put_carried = pd0.sr_ptr != nullptr;
                         if (L0.binv_fmt == 2)
                             hipLaunchKernelGGL((k_bfirst_bicg<2, 2>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows,
                                                (const void*)L0.binv32, L0.omega, z1, sc, (const double*)ph, (const double*)sh,
-                                               (const double*)t, (const double*)v, x, r, p, s);
+                                               (const double*)t, (const double*)v, x, r, p, s, pd0);
                         else
                             hipLaunchKernelGGL((k_bfirst_bicg<1, 2>), dim3(gb), dim3(256), 0, h->stream, ns, L0.blk_rows,
                                                (const void*)L0.binv32, L0.omega, z1, sc, (const double*)ph, (const double*)sh,
-                                               (const double*)t, (const double*)v, x, r, p, s);
+                                               (const double*)t, (const double*)v, x, r, p, s, pd0);
                     } else {
                         hipLaunchKernelGGL(k_bicg_xrp_first, dim3(g), dim3(256), 0, h->stream, nd, sc, ph, sh, s, t, v, x, r, p,
                                            L0.dinv32, L0.omega, z1);
@@ -412,6 +418,8 @@ int fgmres(sns_ctx* h, const double* b, double* x, int* its_out, int* reason_out
 int krylov(sns_ctx* h, const double* b, double* x, int* its, int* reason, double* rnorm) {
     if (!h->has_matrix) { set_error("krylov_solve before a matrix was assembled"); return SNS_E_STATE; }
     if (!h->pc_ready && h->opt.pc_type != SNS_PC_NONE) SNS_TRY(pc_setup(h));
+    h->first_put_carried = h->child_put_carried = h->pc_then_op = false;
+    h->put_pending = nullptr;
     h->first_sweep_done = false;                 // (a solve that ended in an error between setting and consuming it must not leak it)
     h->ctr_host_syncs = h->ctr_allreduce = h->ctr_exchange = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));

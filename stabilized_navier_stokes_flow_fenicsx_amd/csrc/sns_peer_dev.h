@@ -80,6 +80,23 @@ struct AgGet {
     long long timeout_ticks = 0;
 };
 
+// The put half of a halo exchange carried by the kernel that PRODUCES the vector (round 5): every lane that writes entry (row, c)
+// of the vector also stores it into the receive windows of the neighbours the row is sent to (sr_ptr / sr_dst: per owned row its
+// send entries, neighbour k << 27 | slot in k's segment), and the last workgroup to finish raises the flags and stores the round --
+// what k_halo_put does in a launch of its own, minus the launch.  sr_ptr == nullptr: off.
+struct PutDst {
+    const int32_t* sr_ptr = nullptr;
+    const int32_t* sr_dst = nullptr;
+    double* const* put = nullptr;                // [2][nn] remote payload addresses, by parity of the round
+    unsigned long long* const* rflag = nullptr;  // [nn] remote flags (nullptr, team transport: the host barrier orders the rounds)
+    unsigned long long* seq = nullptr;           // the plan's round (device word): this kernel runs round *seq + 1 and stores it
+    unsigned int* done = nullptr;
+    // workgroups of the producing kernel that hold a sent row, for its two slot groupings (64 / 8 block slots per workgroup): ONLY
+    // those count themselves -- every workgroup of a 3400-workgroup pass adding to one counter costs ~30 us of same-address atomics
+    const unsigned int* expect = nullptr;
+    int nn = 0;
+};
+
 __device__ __forceinline__ void peer_flag_store(unsigned long long* f, unsigned long long v) {
     __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -132,6 +149,38 @@ struct GhostReader {
         waited = true;
     }
 };
+
+__device__ __forceinline__ unsigned long long put_begin(const PutDst& pd) {
+    return pd.sr_ptr ? __hip_atomic_load(pd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull : 0ull;
+}
+// entry (row, c) of the produced vector -> the neighbours' receive windows; returns whether anything was stored
+__device__ __forceinline__ bool put_store(const PutDst& pd, unsigned long long seq, int32_t row, int c, double val) {
+    const int32_t e0 = pd.sr_ptr[row], e1 = pd.sr_ptr[row + 1];
+    for (int32_t e = e0; e < e1; ++e) {
+        const int32_t d = pd.sr_dst[e];
+        pd.put[(size_t)(seq & 1ull) * pd.nn + (d >> 27)][4 * (int64_t)(d & 0x7ffffff) + c] = val;
+    }
+    return e1 > e0;
+}
+// called by ALL threads of every workgroup after their stores (s_last: a workgroup-shared int)
+// (grouping: 0 = 64 block slots per workgroup, 1 = 8)
+__device__ __forceinline__ void put_finish(const PutDst& pd, unsigned long long seq, bool stored, int* s_last, int grouping) {
+    if (!__syncthreads_or(stored ? 1 : 0)) return;         // (uniform over the workgroup)
+    if (pd.rflag) __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *s_last = (atomicAdd(pd.done, 1u) + 1u == pd.expect[grouping]) ? 1 : 0;
+    __syncthreads();
+    if (*s_last) {
+        if (pd.rflag) {
+            __threadfence_system();
+            if ((int)threadIdx.x < pd.nn) peer_flag_store(pd.rflag[threadIdx.x], seq);
+        }
+        if (threadIdx.x == 0) {
+            *pd.done = 0u;
+            __hip_atomic_store(pd.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // Sum v[0..count) over the ranks, result back in v (workgroup-shared or global memory; count <= PEER_AR_MAX).  Called by ALL
 // threads of one workgroup of >= max(nranks, count) threads.  Contribution into every rank's slot table, flags, wait for

@@ -1130,6 +1130,12 @@ int pc_setup(sns_ctx* h) {
             return SNS_E_STATE;
         }
     }
+    if (h->comm && h->comm->peer && h->opt.pc_type == SNS_PC_AMG)
+        for (int l = 0; l < nl && l < (int)h->comm->plans.size(); ++l) {
+            const Level& L = h->levels[l];
+            if (L.blk_rows && L.n_blk > 0 && L.binv32)        // the puts carried by this level's block kernels (comm_put_dst)
+                SNS_TRY(comm_plan_put_groups(h->comm.get(), h->comm->plans[l], L.blk_rows, 8 * L.n_blk, h->stream));
+        }
     h->pc_ready = true;
     return SNS_OK;
 }
