@@ -702,8 +702,9 @@ inline void level_sweeps(const sns_ctx* h, int l, int& nu_pre, int& nu_post) {
     const int ll = (h->rep_level > 0 && l >= h->rep_level) ? l - 1 : l;
     // rank-local sweeps: a partitioned handle (any level: the rule of rounds 2-4) unless the level's sweeps are the exact global
     // ones (level_exact: then it IS the single-GPU cycle)
-    const bool rank_local = h->comm && h->comm->active() && h->comm->nranks > 1 && !level_exact(h, l);
-    const policy::Sweeps s = policy::level_sweeps(h->opt, ll, block_active(h, l), rank_local, level_nu(h, l));
+    const bool part = h->comm && h->comm->active() && h->comm->nranks > 1;
+    const bool exact = part && level_exact(h, l);
+    const policy::Sweeps s = policy::level_sweeps(h->opt, ll, block_active(h, l), part && !exact, level_nu(h, l), exact);
     nu_pre = s.pre;
     nu_post = s.post;
 }

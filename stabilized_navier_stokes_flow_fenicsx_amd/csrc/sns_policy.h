@@ -94,14 +94,17 @@ inline int level_nu(const sns_options& o, int ll, bool blocks, const ExtraSweeps
 // sweeps before / after the coarse-grid correction (the first pre-sweep is w S b from the zero guess).  Level 1: asymmetric --
 // post-smoothing is the more valuable half under a piecewise-constant prolongation: 1 + amg_bnu_l1 with aggregate blocks,
 // 1 + (nu + 2) with nodal blocks -- UNLESS its sweeps are rank-local (a partitioned level whose sweeps do not see the neighbours'
-// iterate: nu + nu there, 1 + 6 costs 8-11 % more iterations).  amg_nu_l1_pre / _post fix the counts.
+// iterate: nu + nu there, 1 + 6 costs 8-11 % more iterations).  A PARTITIONED level 1 with exact global sweeps (exact_partitioned)
+// runs one post-sweep more, 1 + (amg_bnu_l1 + 1): its rows per rank are few, a sweep costs ~11 us, and the 4- / 8-way split of the
+// 10 M-tet duct needs 91 / 89 instead of 98 / 95 iterations for it (profiles/r5_l1_schedules.txt; 4 + 4 rank-local: 91 / 97).
+// amg_nu_l1_pre / _post fix the counts.
 struct Sweeps { int pre = 1, post = 1; };
-inline Sweeps level_sweeps(const sns_options& o, int ll, bool blocks, bool rank_local_sweeps, int nu) {
+inline Sweeps level_sweeps(const sns_options& o, int ll, bool blocks, bool rank_local_sweeps, int nu, bool exact_partitioned = false) {
     Sweeps s;
     s.pre = s.post = nu;
     if (ll == 1) {
         if (blocks) {
-            if (!rank_local_sweeps) { s.pre = 1; s.post = std::max(1, o.amg_bnu_l1); }
+            if (!rank_local_sweeps) { s.pre = 1; s.post = std::max(1, o.amg_bnu_l1) + (exact_partitioned ? 1 : 0); }
         } else if (o.amg_nu_l1_pre == 0 && o.amg_nu_l1_post == 0 && !rank_local_sweeps && nu >= 2) {
             s.pre = 1;
             s.post = nu + 2;
@@ -147,7 +150,7 @@ inline void cycle_table(const sns_options& o, int nranks, bool windows, int nlev
                    o.amg_fuse_restrict != 0 && !(o.amg_sweep_exchange_rows > 0))
                       ? 1 : 0;
         const int nu = level_nu(o, ll, blocks, e);
-        const Sweeps s = level_sweeps(o, ll, blocks, partitioned_level && !r.exact, nu);
+        const Sweeps s = level_sweeps(o, ll, blocks, partitioned_level && !r.exact, nu, r.exact != 0);
         r.kind = blocks ? SNS_LEVEL_AGGREGATE_BLOCKS : SNS_LEVEL_NODAL_BLOCKS;
         r.pre = s.pre;
         r.post = s.post;

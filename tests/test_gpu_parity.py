@@ -613,7 +613,7 @@ def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
     """Round 5: the window form of the partitioned cycle (halo_windows: one put launch per exchange, the level passes read their
     ghost entries from the receive window) with a PARTITIONED, aggregate-block-smoothed level 1 above the replicated tail
     (amg_replicate_rows lowered so that the 96 x 24 x 24 duct has one): amg_exact_sweeps = 1 runs the single-GPU schedule there
-    (1 + 3 exact global sweeps, the correction inside the first post-sweep, its coarse solution read straight from the
+    (exact global sweeps, 1 + 4 = one post-sweep more than the single GPU's 1 + 3; the correction inside the first post-sweep, its coarse solution read straight from the
     replicated level), = 0 round 4's 4 + 4 rank-local sweeps; halo_windows = 0 is round 4's exchange.  All three reach the serial
     fields; the exact cycle needs the iterations of the serial solve."""
     from stabilized_navier_stokes_flow_fenicsx_amd import partition as PT
@@ -664,7 +664,7 @@ def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
             if row["kind"] >= 0:
                 assert (row["kind"], row["pre"], row["post"]) == ran or (l == len(rows0) - 1 and row["kind"] == ran[0]), (name, l, row, ran)
     cyc_e, cyc_l = res["exact"][5], res["local"][5]
-    assert cyc_e[1][0] == 1 and (cyc_e[1][1], cyc_e[1][2]) == (1, 3), cyc_e           # partitioned level 1: aggregate blocks, 1 + 3
+    assert cyc_e[1][0] == 1 and (cyc_e[1][1], cyc_e[1][2]) == (1, 4), cyc_e           # partitioned level 1: aggregate blocks, 1 + (3 + 1)
     assert (cyc_l[1][1], cyc_l[1][2]) == (4, 4) and res["round4"][5] == cyc_l, cyc_l
     # the exact cycle IS the single-GPU cycle (up to the aggregates, which never cross ranks): it needs the serial solve's iterations
     # (4 + 4 rank-local sweeps are twice the sweeps per cycle: fewer iterations on a mesh this small, for 9 instead of 5 launches)

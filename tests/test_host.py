@@ -723,7 +723,7 @@ def test_hierarchy_policy_table(built_lib):
     assert rccl == [(1, 1, 1), (1, 4, 4), (-1, 0, 0), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
     # ... over a window transport with amg_exact_sweeps (round 5): level 1 runs the single-GPU schedule with exact sweeps
     win = _lib.host_cycle_policy(part, nranks=8, windows=True, rep_level=3, rows_global_l1=218044)
-    assert [(r["kind"], r["pre"], r["post"]) for r in win] == [(1, 1, 1), (1, 1, 3), (-1, 0, 0), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
+    assert [(r["kind"], r["pre"], r["post"]) for r in win] == [(1, 1, 1), (1, 1, 4), (-1, 0, 0), (1, 4, 4), (1, 2, 2), (1, 2, 2), (3, 0, 0)]
     assert [r["exact"] for r in win] == [0, 1, 0, 0, 0, 0, 0]
     assert T(part, nranks=8, windows=True, rep_level=3, rows_global_l1=218044, amg_exact_sweeps=0) == rccl
     # 2 ranks: 869 k rows per rank keep the nodal fine level
