@@ -175,7 +175,8 @@ typedef struct {
                                Needs amg_f32_matrix != 0 and amg_agg_size <= 8; levels where it does not apply keep the nodal
                                blocks and their sweep counts.  Fixed when the hierarchy is built */
     int    amg_bnu_l1;      /* sweeps after the coarse-grid correction on level 1 under amg_block_smooth (3; one sweep before it);
-                               a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*) */
+                               a partitioned handle runs amg_bnu_l2 + amg_bnu_l2 there (rank-local post-sweeps, as with amg_nu_l1_*),
+                               or, with exact global sweeps (amg_exact_sweeps over a window transport), 1 + (amg_bnu_l1 + 1) */
     int    amg_bnu_l2;      /* sweeps per half cycle on level 2 under amg_block_smooth (4) */
     int    amg_bnu_deep;    /* ... and on levels >= 3 (2: the nodal blocks' count, with the stronger smoother).  amg_nu_scale_with_size adds half of its extra sweeps (rounded up) to both */
     int    amg_ritz_limit;  /* 1 (default): on every level that runs 3 or more sweeps per cycle the damping is also capped by the
@@ -209,11 +210,11 @@ typedef struct {
     /* (retired in round 5, VERDICT r4 item 6: amg_fine_cycle -- the experimental V(0,1) / V(1,0) fine-level cycles, never the default
        and untested since round 3 --, amg_growth_check -- its value 1 is the rule now, csrc/sns_setup.hip) */
     int    amg_exact_sweeps; /* (round 5) 1 (default): on the window transports the aggregate-block-smoothed PARTITIONED levels >= 1 run
-                               the single-GPU schedule (level 1: 1 + amg_bnu_l1 sweeps, the coarse-grid correction inside the first
-                               post-sweep) with EXACT global sweeps -- one put per sweep, which costs one small launch there --
-                               instead of amg_bnu_l2 + amg_bnu_l2 rank-local sweeps with an unfused correction (8-way split of the
-                               10 M-tet duct: 34 / 36 instead of 36 / 36 BiCGStab iterations with 5 instead of 9 level-1 launches per
-                               cycle).  0, and always over RCCL (an exchange per sweep costs a send / recv group there): round 4's cycle */
+                               the single-GPU schedule (level 1: 1 + (amg_bnu_l1 + 1) sweeps, the coarse-grid correction inside the
+                               first post-sweep) with EXACT global sweeps -- a flag wait per sweep, the put rides in the kernel that
+                               produces the iterate -- instead of amg_bnu_l2 + amg_bnu_l2 rank-local sweeps with an unfused
+                               correction (8-way split of the 10 M-tet duct: 31 / 34 instead of 36 / 36 BiCGStab iterations with 6
+                               instead of 9 level-1 launches per cycle).  0, and always over RCCL (an exchange per sweep costs a send / recv group there): round 4's cycle */
 } sns_options;
 
 SNS_API void sns_default_options(sns_options* opt);

@@ -609,7 +609,7 @@ def test_two_stream_halo_overlap_matches_exchange_then_full_pass(gpu, nranks, mo
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
-def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
+def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks, monkeypatch):
     """Round 5: the window form of the partitioned cycle (halo_windows: one put launch per exchange, the level passes read their
     ghost entries from the receive window) with a PARTITIONED, aggregate-block-smoothed level 1 above the replicated tail
     (amg_replicate_rows lowered so that the 96 x 24 x 24 duct has one): amg_exact_sweeps = 1 runs the single-GPU schedule there
@@ -627,8 +627,14 @@ def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
     Us, ws = Us.cpu().numpy(), ws.cpu().numpy()
     Ps.close()
     res, res_all = {}, {}
-    for name, kw in (("exact", dict(halo_windows=1, amg_exact_sweeps=1)), ("local", dict(halo_windows=1, amg_exact_sweeps=0)),
-                     ("round4", dict(halo_windows=0, amg_exact_sweeps=0))):
+    for name, kw in (("exact", dict(halo_windows=1, amg_exact_sweeps=1)), ("exact, separate puts", dict(halo_windows=1, amg_exact_sweeps=1)),
+                     ("local", dict(halo_windows=1, amg_exact_sweeps=0)), ("round4", dict(halo_windows=0, amg_exact_sweeps=0))):
+        # the put of an exchange rides in the kernel that produces the vector (PutDst); SNS_NO_CARRIED_PUT (read when a handle is
+        # made) keeps the separate k_halo_put launch: the same stores by another kernel, so the results must agree BITWISE
+        if name == "exact, separate puts":
+            monkeypatch.setenv("SNS_NO_CARRIED_PUT", "1")
+        else:
+            monkeypatch.delenv("SNS_NO_CARRIED_PUT", raising=False)
         team = Team(nranks)
 
         def work(rank, team):
@@ -663,6 +669,8 @@ def test_window_cycle_with_exact_coarse_sweeps(gpu, nranks):
         for l, (row, ran) in enumerate(zip(table, res[name][5])):
             if row["kind"] >= 0:
                 assert (row["kind"], row["pre"], row["post"]) == ran or (l == len(rows0) - 1 and row["kind"] == ran[0]), (name, l, row, ran)
+    for a, b in zip(res_all["exact"], res_all["exact, separate puts"]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and (a[2].its, a[4].ksp_its) == (b[2].its, b[4].ksp_its)
     cyc_e, cyc_l = res["exact"][5], res["local"][5]
     assert cyc_e[1][0] == 1 and (cyc_e[1][1], cyc_e[1][2]) == (1, 4), cyc_e           # partitioned level 1: aggregate blocks, 1 + (3 + 1)
     assert (cyc_l[1][1], cyc_l[1][2]) == (4, 4) and res["round4"][5] == cyc_l, cyc_l

@@ -97,6 +97,22 @@ def test_partitioned_solve_between_processes_over_peer_windows(kind, world, opts
         assert max(len(r["neighbors"]) for r in res) == 3
 
 
+def test_carried_puts_match_separate_put_launches_between_processes(tmp_path):
+    """Round 5: the put half of a halo exchange rides in the kernel that produces the vector (PutDst: stores into the neighbours'
+    windows next to the local store, the last storing workgroup fences and raises the flags).  SNS_NO_CARRIED_PUT keeps the
+    separate k_halo_put launch.  Four processes over mapped windows, both ways: the same iterations, decisions and errors."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    ra = _run_ranks("cavity", 4, tmp_path / "a")
+    rb = _run_ranks("cavity", 4, tmp_path / "b", env_extra={"SNS_NO_CARRIED_PUT": "1"})
+    for a, b in zip(ra, rb):
+        assert a["ok"] and b["ok"]
+        for k in ("stokes_its", "ksp_its", "newton_its", "levels", "cycle", "err_spmv", "err_stokes", "err_newton"):
+            assert a[k] == b[k], (k, a[k], b[k])
+    # with the puts carried an exchange is counted all the same, only the launch is gone
+    assert ra[0]["exchanges"] == rb[0]["exchanges"]
+
+
 def test_a_rank_that_never_arrives_is_an_error_not_a_hang(tmp_path):
     res = _run_ranks("duct-late", 3, tmp_path, env_extra={"SNS_PEER_TIMEOUT_MS": "3000"}, deadline=300.0)
     late = [r for r in res if r.get("skipped")]
