@@ -224,7 +224,7 @@ SNS_API const char* sns_version(void);
  * and the fixed-size out-arrays of the getters below have grown (sns_get_counters / sns_get_kernel_times: 4 -> 8 entries in
  * round 3), so a binding built against an older header would pass short buffers: bindings compare both numbers with the
  * header they were written against before making any other call (the ctypes mirror does, _lib.py) and refuse on a mismatch. */
-#define SNS_ABI_VERSION 6
+#define SNS_ABI_VERSION 7
 SNS_API int sns_abi_version(void);
 SNS_API int64_t sns_options_size(void);
 
@@ -454,6 +454,13 @@ SNS_API int sns_host_pattern(int32_t n_nodes, int64_t n_tets, const int32_t* tet
  * agg_out[n_nodes] gets the aggregate id (-1 for inactive nodes).             */
 SNS_API int sns_host_aggregate(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind,
                        int32_t n_active, int max_agg, int32_t* agg_out, int32_t* n_agg_out);
+/* (round 5) ... with the nodes' coordinates pts[3 * n_nodes], as the hierarchy build runs it on a 3-D level: the greedy sweep
+ * (on an anisotropic cloud along the short edges only), and -- unless its aggregates are as compact as cubes already -- a pairwise
+ * aggregation (nodes -> pairs -> quadruples -> octets by closest centroids), which does not depend on how the node numbers run
+ * through the mesh; the more compact of the two is returned.  *which_out: 0 = greedy sweep, 1 = pairwise.  pts = NULL: the
+ * greedy sweep, = sns_host_aggregate.                                          */
+SNS_API int sns_host_aggregate_pts(int32_t n_nodes, const int32_t* rowptr, const int32_t* colind, int32_t n_active, int max_agg,
+                           const double* pts, int32_t* agg_out, int32_t* n_agg_out, int32_t* which_out);
 
 /* owned rows (i < n_owned) of a local pattern that reference a ghost column (>= n_owned): the boundary rows of the
  * interior / boundary split of the multi-GPU SpMV -- interior rows are computed while the halo is in flight

@@ -60,7 +60,7 @@ class SnsTimings(C.Structure):
 
 
 # constants of sns.h
-ABI_VERSION = 6                          # SNS_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 7                          # SNS_ABI_VERSION of the header this mirror was written against
 FORM_STOKES, FORM_NS = 0, 1
 KSP_BICGSTAB, KSP_FGMRES, KSP_TFQMR = 0, 1, 2
 PC_NONE, PC_BJACOBI, PC_AMG = 0, 1, 2
@@ -127,6 +127,7 @@ _SIGNATURES = [
                                   C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     ("sns_host_pattern", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("sns_host_aggregate", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, C.POINTER(C.c_int32)]),
+    ("sns_host_aggregate_pts", C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("sns_host_boundary_rows", C.c_int, [C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     ("sns_host_cycle_policy", C.c_int, [C.POINTER(SnsOptions), C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P]),
     ("sns_host_hessenberg_eigs", C.c_int, [C.c_int, _P, _P, _P]),
@@ -196,7 +197,9 @@ def host_pattern(n_nodes: int, tets):
     return rowptr, colind, c_ptr, c_idx
 
 
-def host_aggregate(rowptr, colind, n_active=None, max_agg=8):
+def host_aggregate(rowptr, colind, n_active=None, max_agg=8, pts=None):
+    """(agg, n_agg) of the greedy sweep; with node coordinates ``pts`` (n, 3): (agg, n_agg, which) of the level's aggregation as
+    the hierarchy build runs it (which = 0 greedy sweep, 1 pairwise: sns_host_aggregate_pts)."""
     import numpy as np
     lib = load()
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -204,9 +207,15 @@ def host_aggregate(rowptr, colind, n_active=None, max_agg=8):
     n = len(rowptr) - 1
     agg = np.empty(n, np.int32)
     nc = C.c_int32()
-    check(lib.sns_host_aggregate(n, rowptr.ctypes.data, colind.ctypes.data, n if n_active is None else n_active,
-                                 max_agg, agg.ctypes.data, C.byref(nc)))
-    return agg, nc.value
+    if pts is None:
+        check(lib.sns_host_aggregate(n, rowptr.ctypes.data, colind.ctypes.data, n if n_active is None else n_active,
+                                     max_agg, agg.ctypes.data, C.byref(nc)))
+        return agg, nc.value
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(n, 3)
+    which = C.c_int32()
+    check(lib.sns_host_aggregate_pts(n, rowptr.ctypes.data, colind.ctypes.data, n if n_active is None else n_active,
+                                     max_agg, pts.ctypes.data, agg.ctypes.data, C.byref(nc), C.byref(which)))
+    return agg, nc.value, which.value
 
 
 def host_boundary_rows(n_owned: int, rowptr, colind):

@@ -7,6 +7,9 @@
 // (tet, a, b) -> block-slot relation is resolved ONCE and inverted, so the
 // device never searches and never needs atomics.
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <complex>
 #include <cstring>
 #include <numeric>
@@ -151,15 +154,147 @@ bool cloud_is_anisotropic(const HostPattern& F, int32_t n_active, const double* 
     return ratio[ratio.size() / 2] > ANISO_ON;
 }
 
+namespace {
+
+// how compact a set of aggregates is: total scatter of the nodes about their aggregates' centroids, made independent of the
+// NUMBER of aggregates (n clusters of a cloud of fixed volume scatter like n^(-2/3) each): lower = more compact
+double scatter_score(const std::vector<int32_t>& agg, int32_t nc, int32_t n_active, const double* pts) {
+    if (nc <= 0) return 1e300;
+    std::vector<double> c((size_t)3 * nc, 0.0);
+    std::vector<int32_t> cnt((size_t)nc, 0);
+    for (int32_t i = 0; i < n_active; ++i) {
+        const int32_t a = agg[i];
+        if (a < 0 || a >= nc) continue;
+        for (int k = 0; k < 3; ++k) c[3 * (size_t)a + k] += pts[3 * (size_t)i + k];
+        ++cnt[a];
+    }
+    for (int32_t a = 0; a < nc; ++a)
+        if (cnt[a]) for (int k = 0; k < 3; ++k) c[3 * (size_t)a + k] /= cnt[a];
+    double w = 0.0;
+    for (int32_t i = 0; i < n_active; ++i) {
+        const int32_t a = agg[i];
+        if (a < 0 || a >= nc) continue;
+        for (int k = 0; k < 3; ++k) { const double d = pts[3 * (size_t)i + k] - c[3 * (size_t)a + k]; w += d * d; }
+    }
+    return w * std::pow((double)nc, 2.0 / 3.0);
+}
+
+// Pairwise aggregation (round 5): log2(max_agg) rounds in which every cluster is matched with the CLOSEST adjacent cluster that is
+// still unmatched (centroid distance; on an anisotropic cloud only within ANISO_KEEP x its closest neighbour cluster), nodes ->
+// pairs -> quadruples -> octets.  Unlike the greedy sweep its aggregates do not depend on how the node numbers run through the
+// mesh: the greedy sweep takes the free neighbours AHEAD of its front, which on a Kuhn lattice numbered along the cells' common
+// diagonal are exactly the seven other corners of a cube -- and on the same lattice numbered against it a sheared box three nodes
+// wide, for 41 % more Krylov iterations (profiles/r5_prism_vs_kuhn.txt).  Leftover single nodes join their closest neighbour cluster.
+void aggregate_pairwise(const HostPattern& F, int32_t n_active, int max_agg, const double* pts, bool strong_only,
+                        std::vector<int32_t>& agg, int32_t& nc) {
+    std::vector<int32_t> of((size_t)F.n, -1);
+    for (int32_t i = 0; i < n_active; ++i) of[i] = i;
+    int32_t ncl = n_active;
+    std::vector<int32_t> ptr, idx, size_, newid, adj;
+    std::vector<double> cen;
+    std::vector<uint8_t> matched;
+    auto members = [&]() {
+        ptr.assign((size_t)ncl + 1, 0);
+        for (int32_t i = 0; i < n_active; ++i) ++ptr[(size_t)of[i] + 1];
+        for (int32_t c = 0; c < ncl; ++c) ptr[(size_t)c + 1] += ptr[c];
+        idx.resize((size_t)n_active);
+        std::vector<int32_t> at(ptr.begin(), ptr.end() - 1);
+        for (int32_t i = 0; i < n_active; ++i) idx[(size_t)at[of[i]]++] = i;
+        cen.assign((size_t)3 * ncl, 0.0);
+        size_.assign((size_t)ncl, 0);
+        for (int32_t c = 0; c < ncl; ++c) {
+            size_[c] = ptr[(size_t)c + 1] - ptr[c];
+            for (int32_t m = ptr[c]; m < ptr[(size_t)c + 1]; ++m)
+                for (int k = 0; k < 3; ++k) cen[3 * (size_t)c + k] += pts[3 * (size_t)idx[m] + k];
+            if (size_[c]) for (int k = 0; k < 3; ++k) cen[3 * (size_t)c + k] /= size_[c];
+        }
+    };
+    auto cdist2 = [&](int32_t a, int32_t b) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) { const double d = cen[3 * (size_t)a + k] - cen[3 * (size_t)b + k]; d2 += d * d; }
+        return d2;
+    };
+    auto neighbours = [&](int32_t a) {                          // clusters adjacent to a, ascending, without a
+        adj.clear();
+        for (int32_t m = ptr[a]; m < ptr[(size_t)a + 1]; ++m) {
+            const int32_t i = idx[m];
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t j = F.colind[k];
+                if (j >= n_active) continue;
+                const int32_t b = of[j];
+                if (b != a) adj.push_back(b);
+            }
+        }
+        std::sort(adj.begin(), adj.end());
+        adj.erase(std::unique(adj.begin(), adj.end()), adj.end());
+    };
+    for (int round = 1; (1 << round) <= max_agg; ++round) {
+        members();
+        matched.assign((size_t)ncl, 0);
+        newid.assign((size_t)ncl, -1);
+        int32_t nnew = 0;
+        for (int32_t a = 0; a < ncl; ++a) {
+            if (matched[a]) continue;
+            neighbours(a);
+            double lo = 1e300;
+            for (int32_t b : adj) lo = std::min(lo, cdist2(a, b));
+            const double lim = strong_only ? ANISO_KEEP * lo * (1.0 + 1e-9) : 1e300;
+            int32_t best = -1;
+            double bd = 1e300;
+            for (int32_t b : adj) {
+                if (matched[b] || size_[a] + size_[b] > max_agg) continue;
+                const double d2 = cdist2(a, b);
+                if (d2 > lim) continue;
+                if (best < 0 || d2 < bd * (1.0 - 1e-12)) { best = b; bd = d2; }
+            }
+            matched[a] = 1;
+            newid[a] = nnew;
+            if (best >= 0) { matched[best] = 1; newid[best] = nnew; }
+            ++nnew;
+        }
+        for (int32_t i = 0; i < n_active; ++i) of[i] = newid[of[i]];
+        ncl = nnew;
+    }
+    // single nodes left over join the closest adjacent cluster (the greedy sweep's rule for a node without a free neighbour)
+    members();
+    newid.assign((size_t)ncl, -1);
+    std::vector<int32_t> target((size_t)ncl, -1);
+    for (int32_t a = 0; a < ncl; ++a) {
+        if (size_[a] != 1) continue;
+        neighbours(a);
+        double lo = 1e300;
+        for (int32_t b : adj) lo = std::min(lo, cdist2(a, b));
+        const double lim = strong_only ? ANISO_KEEP * lo * (1.0 + 1e-9) : 1e300;
+        int32_t best = -1;
+        double bd = 1e300;
+        for (int32_t b : adj) {
+            if (size_[b] < 2 || target[b] >= 0) continue;       // (not another single node, nor one that has moved)
+            const double d2 = cdist2(a, b);
+            if (d2 > lim) continue;
+            if (best < 0 || d2 < bd * (1.0 - 1e-12)) { best = b; bd = d2; }
+        }
+        target[a] = best;
+    }
+    int32_t nnew = 0;
+    for (int32_t a = 0; a < ncl; ++a)
+        if (target[a] < 0) newid[a] = nnew++;
+    for (int32_t a = 0; a < ncl; ++a)
+        if (target[a] >= 0) newid[a] = newid[target[a]];
+    agg.assign((size_t)F.n, -1);
+    for (int32_t i = 0; i < n_active; ++i) agg[i] = newid[of[i]];
+    nc = nnew;
+}
+
+}  // namespace
+
 // Size-limited greedy aggregation.  With `pts` (3 coordinates per node of the level) on an ANISOTROPIC cloud a node only takes
 // (or joins) neighbours within 2x its shortest edge -- the strong couplings of a diffusion-dominated operator scale with
 // 1 / length^2, the block-Jacobi smoother handles exactly those, and aggregating along them alone is the semi-coarsening such
 // meshes need; on every other cloud (all of rounds 1-4's meshes) the filter is off and the aggregates are those of round 1.
-void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
-                            int32_t& nc, const double* pts) {
+static void aggregate_greedy(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
+                             int32_t& nc, const double* pts, bool strong_only) {
     agg.assign((size_t)F.n, -1);
     nc = 0;
-    const bool strong_only = cloud_is_anisotropic(F, n_active, pts);
     auto dist2 = [&](int32_t i, int32_t j) {
         double d2 = 0.0;
         for (int c = 0; c < 3; ++c) { const double d = pts[3 * (size_t)j + c] - pts[3 * (size_t)i + c]; d2 += d * d; }
@@ -186,6 +321,55 @@ void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::v
         }
         if (taken == 0 && first_agg_nb >= 0) { agg[i] = first_agg_nb; continue; }
         agg[i] = nc++;
+    }
+}
+
+// The aggregation of a level.  Without coordinates: the greedy sweep.  With coordinates: the greedy sweep AND the pairwise
+// aggregation; the pairwise one is taken when its aggregates are more compact by more than 5 % (scatter_score) -- on the Kuhn
+// lattices numbered along their diagonal the sweep's aggregates are cubes already and stay what they were in rounds 1-4.
+// SNS_AGGREGATION=greedy|pairwise forces one (experiments); `which`, if given, reports the choice (0 greedy, 1 pairwise).
+void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg,
+                     int32_t& nc, const double* pts, int* which) {
+    const bool strong_only = cloud_is_anisotropic(F, n_active, pts);
+    aggregate_greedy(F, n_active, max_agg, agg, nc, pts, strong_only);
+    if (which) *which = 0;
+    const char* force = std::getenv("SNS_AGGREGATION");
+    if (!pts || n_active < 64 || max_agg < 2 || (force && force[0] == 'g')) return;
+    // (the sweep's aggregates are as compact as cubes already -- the Kuhn lattices numbered along their diagonal, i.e. every
+    // structured mesh of rounds 1-4: scatter per node at most 0.85 x (mean squared shortest edge) x (nodes per aggregate / 8)^(2/3),
+    // a 2 x 2 x 2 cube has 0.75 --: nothing to gain, and the second aggregation of a 100 M-node level is not free)
+    if (!(force && force[0] == 'p')) {
+        const int32_t step = std::max(1, n_active / 50000);
+        double lo_sum = 0.0;
+        int64_t cnt = 0;
+        for (int32_t i = 0; i < n_active; i += step) {
+            double lo = 1e300;
+            for (int32_t k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                const int32_t j = F.colind[k];
+                if (j == i) continue;
+                double d2 = 0.0;
+                for (int c = 0; c < 3; ++c) { const double d = pts[3 * (size_t)j + c] - pts[3 * (size_t)i + c]; d2 += d * d; }
+                lo = std::min(lo, d2);
+            }
+            if (lo < 1e300) { lo_sum += lo; ++cnt; }
+        }
+        if (cnt > 0 && nc > 0) {
+            const double w_per_node = scatter_score(agg, nc, n_active, pts) / std::pow((double)nc, 2.0 / 3.0) / (double)n_active;
+            if (w_per_node <= 0.85 * lo_sum / (double)cnt * std::pow((double)n_active / (double)nc / 8.0, 2.0 / 3.0)) return;
+        }
+    }
+    std::vector<int32_t> agg2;
+    int32_t nc2 = 0;
+    aggregate_pairwise(F, n_active, max_agg, pts, strong_only, agg2, nc2);
+    if (nc2 <= 0 || nc2 >= n_active) return;
+    const double sg = scatter_score(agg, nc, n_active, pts), sp = scatter_score(agg2, nc2, n_active, pts);
+    if (std::getenv("SNS_AGGREGATION_VERBOSE"))
+        std::fprintf(stderr, "[sns] aggregation of %d nodes: greedy %d aggregates, score %.4g; pairwise %d, score %.4g\n", n_active, nc,
+                     sg, nc2, sp);
+    if ((force && force[0] == 'p') || sp < 0.95 * sg) {
+        agg.swap(agg2);
+        nc = nc2;
+        if (which) *which = 1;
     }
 }
 
@@ -397,8 +581,15 @@ extern "C" int sns_host_pattern(int32_t n, int64_t E, const int32_t* tets, int64
     return SNS_OK;
 }
 
+extern "C" int sns_host_aggregate_pts(int32_t n, const int32_t* rowptr, const int32_t* colind, int32_t n_active,
+                                      int max_agg, const double* pts, int32_t* agg_out, int32_t* n_agg_out, int32_t* which_out);
 extern "C" int sns_host_aggregate(int32_t n, const int32_t* rowptr, const int32_t* colind, int32_t n_active,
                                   int max_agg, int32_t* agg_out, int32_t* n_agg_out) {
+    return sns_host_aggregate_pts(n, rowptr, colind, n_active, max_agg, nullptr, agg_out, n_agg_out, nullptr);
+}
+
+extern "C" int sns_host_aggregate_pts(int32_t n, const int32_t* rowptr, const int32_t* colind, int32_t n_active,
+                                      int max_agg, const double* pts, int32_t* agg_out, int32_t* n_agg_out, int32_t* which_out) {
     if (n <= 0 || !rowptr || !colind || !agg_out || n_active < 0 || n_active > n || max_agg < 1) {
         sns::set_error("sns_host_aggregate: bad arguments");
         return SNS_E_ARG;
@@ -410,9 +601,11 @@ extern "C" int sns_host_aggregate(int32_t n, const int32_t* rowptr, const int32_
     F.colind.assign(colind, colind + F.nnzb);
     std::vector<int32_t> agg;
     int32_t nc = 0;
-    sns::aggregate_nodes(F, n_active, max_agg, agg, nc);
+    int which = 0;
+    sns::aggregate_nodes(F, n_active, max_agg, agg, nc, pts, &which);
     std::copy(agg.begin(), agg.end(), agg_out);
     if (n_agg_out) *n_agg_out = nc;
+    if (which_out) *which_out = which;
     return SNS_OK;
 }
 

@@ -109,7 +109,7 @@ struct Level {
 };
 
 void aggregate_nodes(const HostPattern& F, int32_t n_active, int max_agg, std::vector<int32_t>& agg, int32_t& nc,
-                     const double* pts = nullptr);
+                     const double* pts = nullptr, int* which = nullptr);
 void set_error(const std::string& s);
 
 }  // namespace sns

@@ -97,27 +97,44 @@ def resample_contour(poly: np.ndarray, h: float, corner_deg: float = 20.0) -> np
     return np.concatenate(out)
 
 
-def cross_section(contour_inner, contour_outer, h2: float):
+def cross_section(contour_inner, contour_outer, h2: float, lattice: str = "square"):
     """Triangulation of [-.5, .5]^2 conforming to both contours.  Polygons are (m, 2) in (y, z).  Returns
-    (points (n, 2), tris (e, 3), region (e,): 1 inner stream, 0 band, 2 outer stream, the two contour chains as meshed)."""
+    (points (n, 2), tris (e, 3), region (e,): 1 inner stream, 0 band, 2 outer stream, the two contour chains as meshed).
+
+    Interior points: a SQUARE lattice aligned with the duct (``lattice="square"``, default), every cell cut along the same
+    diagonal, and the points numbered by (z ascending, y descending).  The prisms over such right triangles, cut along
+    diagonals that follow the numbering, are Kuhn cells -- no dihedral angle above 90 degrees, where an equilateral base gives
+    104-117 -- and the numbering runs along the cells' common diagonal, which is what the greedy aggregation of the AMG
+    hierarchy needs to find cube-shaped aggregates (profiles/r5_prism_vs_kuhn.txt: both together are worth a third of the
+    Krylov iterations on a plain duct).  Only the strips along the contours hold general triangles.  ``lattice="hex"``: the
+    hexagonal lattice of the first version."""
     from scipy.spatial import Delaunay, cKDTree
     square = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]])
-    chains = [resample_contour(np.asarray(contour_inner, dtype=np.float64), h2),
-              resample_contour(np.asarray(contour_outer, dtype=np.float64), h2), _resample_closed(square, h2)]
-    bpts = np.concatenate(chains)
-    ny = max(2, int(round(1.0 / (h2 * np.sqrt(3.0) / 2.0))))
     nx = max(2, int(round(1.0 / h2)))
-    jj, ii = np.meshgrid(np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
-    lat = np.stack([-0.5 + (ii + 0.5 * (jj % 2)) / nx, -0.5 + jj / ny], axis=-1).reshape(-1, 2)
+    # (square lattice: the duct wall's points ARE lattice points, so the right triangles reach the wall)
+    chains = [resample_contour(np.asarray(contour_inner, dtype=np.float64), h2),
+              resample_contour(np.asarray(contour_outer, dtype=np.float64), h2),
+              _resample_closed(square, 1.0 / nx if lattice == "square" else h2)]
+    bpts = np.concatenate(chains)
+    if lattice == "square":
+        jj, ii = np.meshgrid(np.arange(nx + 1), np.arange(nx + 1), indexing="ij")
+        lat = np.stack([-0.5 + ii / nx, -0.5 + jj / nx], axis=-1).reshape(-1, 2)
+    else:
+        ny = max(2, int(round(1.0 / (h2 * np.sqrt(3.0) / 2.0))))
+        jj, ii = np.meshgrid(np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+        lat = np.stack([-0.5 + (ii + 0.5 * (jj % 2)) / nx, -0.5 + jj / ny], axis=-1).reshape(-1, 2)
     lat = lat[(np.abs(lat) < 0.5 - 1e-9).all(axis=1)]
     # interior points stay 0.6 h2 away from the chains THEMSELVES (measured to a 4x finer sampling of them): every chain segment is
     # at most h2 long, so its diametral circle (radius <= h2 / 2) is empty and the segment is an edge of the Delaunay triangulation
     fine = np.concatenate([resample_contour(c, 0.25 * h2, corner_deg=0.0) if len(c) > 4 else _resample_closed(c, 0.25 * h2)
                            for c in (np.asarray(contour_inner, dtype=np.float64), np.asarray(contour_outer, dtype=np.float64), square)])
-    d, _ = cKDTree(fine).query(lat)
-    lat = lat[d > 0.6 * h2]
+    d_c, _ = cKDTree(fine[:-len(_resample_closed(square, 0.25 * h2))] if lattice == "square" else fine).query(lat)
+    lat = lat[d_c > 0.6 * h2]                                  # (square lattice: only the two contours exclude, the wall is part of it)
     pts = np.concatenate([bpts, lat])
-    tris = Delaunay(pts).simplices.astype(np.int64)
+    # a tiny shear decides the ties of the square cells (four cocircular points) the same way everywhere: the shorter diagonal of
+    # every sheared cell is the one from (y + 1, z) to (y, z + 1)
+    shear = pts + np.stack([1e-4 * pts[:, 1], np.zeros(len(pts))], axis=1) if lattice == "square" else pts
+    tris = Delaunay(shear).simplices.astype(np.int64)
     a = pts[tris]
     area2 = np.abs((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
     tris = tris[area2 > 1e-3 * h2 * h2]                      # (qhull leaves needle triangles between collinear points of the square's edges)
@@ -139,6 +156,13 @@ def cross_section(contour_inner, contour_outer, h2: float):
     inside_in = points_in_polygon(cen, chains[0])                # (the chains ARE the mesh's nozzle surfaces)
     inside_out = points_in_polygon(cen, chains[1])
     region = np.where(inside_in, 1, np.where(inside_out, 0, 2)).astype(np.int8)
+    if lattice == "square":
+        # number the points by (z ascending, y descending): the right angle of every lattice triangle then sits at its MIDDLE
+        # vertex, which is what makes the three tets of its prism Kuhn cells (nozzle_channel_mesh cuts along the numbering)
+        order = np.lexsort((-np.round(pts[:, 0], 12), np.round(pts[:, 1], 12)))
+        new = np.empty(len(pts), dtype=np.int64)
+        new[order] = np.arange(len(pts))
+        pts, tris = pts[order], new[tris]
     return pts, tris, region, chains[0], chains[1]
 
 

@@ -203,6 +203,60 @@ def test_host_aggregation_covers_and_limits(built_lib):
     assert np.array_equal(agg, agg3)                                           # deterministic
 
 
+def test_aggregation_does_not_depend_on_the_node_numbering(built_lib):
+    """Round 5 (profiles/r5_prism_vs_kuhn.txt): the greedy sweep takes the free neighbours AHEAD of its front.  On a Kuhn lattice
+    numbered along the cells' common diagonal those are the seven other corners of a cube; on the same lattice numbered against it
+    a sheared box three nodes wide (41 % more Krylov iterations on the GPU).  With coordinates the level's aggregation
+    (sns_host_aggregate_pts) keeps the sweep when its aggregates are cube-compact and otherwise compares it with a pairwise
+    aggregation (closest centroids, three rounds) and returns the more compact one."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import _lib
+    from stabilized_navier_stokes_flow_fenicsx_amd.mesh import TetMesh
+    m = M.duct_mesh((31, 15, 15), 31.0 / 15.0)               # 32 x 16 x 16 nodes
+    h = 1.0 / 15
+
+    def scatter_per_node(pts, agg, nc):
+        c = np.stack([np.bincount(agg, weights=pts[:, k], minlength=nc) for k in range(3)], 1) / np.bincount(agg, minlength=nc)[:, None]
+        return ((pts - c[agg]) ** 2).sum() / len(pts)
+
+    def connected(rp, ci, agg, nc):                      # every aggregate is a connected set of the node graph
+        rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        same = agg[rows] == agg[ci]
+        import scipy.sparse as sp
+        import scipy.sparse.csgraph as cg
+        g = sp.coo_matrix((np.ones(same.sum()), (rows[same], ci[same])), shape=(len(agg), len(agg)))
+        ncomp, _ = cg.connected_components(g, directed=False)
+        return ncomp == nc
+
+    rp, ci, _, _ = _lib.host_pattern(m.num_nodes, m.tets)
+    agg, nc, which = _lib.host_aggregate(rp, ci, max_agg=8, pts=m.points)
+    agg0, nc0 = _lib.host_aggregate(rp, ci, max_agg=8)
+    assert which == 0 and nc == nc0 and np.array_equal(agg, agg0)            # aligned numbering: the sweep of rounds 1-4, bit for bit
+    s_aligned = scatter_per_node(m.points, agg, nc)
+    assert s_aligned <= 0.8 * h * h and connected(rp, ci, agg, nc)
+    # the same cells, the nodes numbered against the diagonal (y descending fastest)
+    p = m.points
+    order = np.lexsort((-p[:, 1].round(9), p[:, 2].round(9), p[:, 0].round(9)))
+    new = np.empty(len(p), np.int64)
+    new[order] = np.arange(len(p))
+    m2 = TetMesh(p[order], new[m.tets].astype(np.int32), m.facets, m.facet_tags)
+    rp2, ci2, _, _ = _lib.host_pattern(m2.num_nodes, m2.tets)
+    g_agg, g_nc = _lib.host_aggregate(rp2, ci2, max_agg=8)
+    agg2, nc2, which2 = _lib.host_aggregate(rp2, ci2, max_agg=8, pts=m2.points)
+    s_greedy, s_chosen = scatter_per_node(m2.points, g_agg, g_nc), scatter_per_node(m2.points, agg2, nc2)
+    print(f"  aligned: {nc} aggregates, scatter {s_aligned / h / h:.3f} h^2; against the diagonal: sweep {g_nc} aggregates, {s_greedy / h / h:.3f} h^2 -> "
+          f"{'pairwise' if which2 else 'sweep'} {nc2} aggregates, {s_chosen / h / h:.3f} h^2")
+    assert s_greedy * g_nc ** (2.0 / 3.0) > 1.15 * s_aligned * nc ** (2.0 / 3.0)   # what the numbering costs the sweep (at equal coarsening)
+    assert which2 == 1 and agg2.min() == 0 and agg2.max() == nc2 - 1 and np.bincount(agg2).max() <= 9
+    assert s_chosen * nc2 ** (2.0 / 3.0) < 0.95 * s_greedy * g_nc ** (2.0 / 3.0) and connected(rp2, ci2, agg2, nc2)
+    assert m2.num_nodes / 8.6 < nc2 < m2.num_nodes / 6.0                      # octets, up to the lattice's odd planes
+    again = _lib.host_aggregate(rp2, ci2, max_agg=8, pts=m2.points)
+    assert np.array_equal(again[0], agg2)                                     # deterministic
+    # inactive tail (ghost nodes of a partitioned level) stays out, as in the sweep
+    n_act = m2.num_nodes - 40
+    agg3, nc3, _ = _lib.host_aggregate(rp2, ci2, n_active=n_act, max_agg=8, pts=m2.points)
+    assert np.all(agg3[n_act:] == -1) and agg3[:n_act].min() == 0 and agg3[:n_act].max() == nc3 - 1
+
+
 def test_bad_mesh_is_rejected_on_host(built_lib):
     from stabilized_navier_stokes_flow_fenicsx_amd import _lib
     with pytest.raises(_lib.SnsError):
