@@ -215,7 +215,7 @@ int alloc_coarsest_solver(sns_ctx* h, Level& last) {
 // and cycles the rest of the hierarchy redundantly: no exchanges below R, and the smoothing there is the exact
 // global block-Jacobi instead of a rank-local one (thin partitions lose their convergence on the deep levels
 // otherwise).  `cur` is the local pattern of level R (owned rows, local column ids), collective over the ranks.
-int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_owned) {
+int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_owned, const std::vector<double>& cur_pts) {
     const sns_options& o = h->opt;
     Comm* c = h->comm.get();
     const int nr = c->nranks, me = c->rank;
@@ -326,6 +326,22 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
     SNS_TRY(dev_alloc(&h->rep_brecv, (size_t)maxn * 4 * nr));
     HIP_TRY(hipMemset(h->rep_vsend, 0, (size_t)maxnz * 16 * sizeof(double)));
     HIP_TRY(hipMemset(h->rep_bsend, 0, (size_t)maxn * 4 * sizeof(double)));
+    // the replicated level's node coordinates (all-gathered like its pattern), so that its aggregation sees shapes, not only numbers
+    std::vector<double> gpts;
+    {
+        double have[1] = {cur_pts.size() == (size_t)3 * cur.n ? 0.0 : 1.0};
+        SNS_TRY(global_sum(h, have, 1));
+        if (have[0] == 0.0) {
+            std::vector<double> pm((size_t)3 * maxn, 0.0), pa;
+            for (int32_t i = 0; i < n_owned; ++i)
+                for (int k = 0; k < 3; ++k) pm[3 * (size_t)i + k] = cur_pts[3 * (size_t)i + k];
+            SNS_TRY(host_allgather(h, pm, pa));
+            gpts.resize((size_t)3 * NG);
+            for (int r = 0; r < nr; ++r)
+                for (int32_t i = 0; i < (int32_t)cnt[r]; ++i)
+                    for (int k = 0; k < 3; ++k) gpts[3 * ((size_t)off[r] + i) + k] = pa[(size_t)r * pm.size() + 3 * (size_t)i + k];
+        }
+    }
     // plain serial aggregation below (identical on every rank: same input, deterministic code)
     HostPattern curp = std::move(G);
     int32_t n_own = NG;
@@ -333,8 +349,22 @@ int build_replicated_tail(sns_ctx* h, int R, const HostPattern& cur, int32_t n_o
         if (n_own <= coarsest_rows(o)) break;
         std::vector<int32_t> agg;
         int32_t nc = 0;
-        aggregate_nodes(curp, n_own, std::min(255, std::max(2, o.amg_agg_size)), agg, nc);
+        aggregate_nodes(curp, n_own, std::min(255, std::max(2, o.amg_agg_size)), agg, nc,
+                        gpts.size() == (size_t)3 * n_own ? gpts.data() : nullptr);
         if (nc >= n_own || nc == 0) break;
+        if (gpts.size() == (size_t)3 * n_own) {              // the next level's nodes: the aggregates' centroids
+            std::vector<double> cp((size_t)3 * nc, 0.0);
+            std::vector<int32_t> cn((size_t)nc, 0);
+            for (int32_t i = 0; i < n_own; ++i) {
+                const int32_t I = agg[i];
+                if (I < 0) continue;
+                for (int k = 0; k < 3; ++k) cp[3 * (size_t)I + k] += gpts[3 * (size_t)i + k];
+                ++cn[I];
+            }
+            for (int32_t I = 0; I < nc; ++I)
+                if (cn[I]) for (int k = 0; k < 3; ++k) cp[3 * (size_t)I + k] /= cn[I];
+            gpts = std::move(cp);
+        }
         HostAggregation A;
         build_coarse_from_agg(curp, n_own, agg, nc, nc, A);
         {
@@ -394,7 +424,7 @@ int build_hierarchy(sns_ctx* h, const HostPattern& fine) {
             double fits[1] = {g[0] <= (double)h->n_owned ? 0.0 : 1.0};
             SNS_TRY(global_sum(h, fits, 1));
             if (policy::replicate_from(o, l, (int64_t)g[0], fits[0] == 0.0))
-                return build_replicated_tail(h, l, cur, n_owned);
+                return build_replicated_tail(h, l, cur, n_owned, cur_pts);
         }
         double flag[1] = {n_owned > per_rank_coarse ? 1.0 : 0.0};
         SNS_TRY(global_sum(h, flag, 1));
