@@ -30,5 +30,8 @@ for f, name in ((0.75, "uniform planes at the cross-section size"), (1.5, "unifo
     m, bc, _ = NM.channel_from_image_bodyfitted(img, 0.5, lc)
     run(name, m, bc)
 NM.size_along_x = orig
+for xe in (0.25, 0.1):                                   # a shorter nozzle (the reference's x_extrude is 0.5, image2gmsh3D.py:193)
+    m, bc, _ = NM.channel_from_image_bodyfitted(img, 0.5, lc, x_extrude=xe)
+    run(f"graded planes, nozzle length {xe}", m, bc)
 ms, bcs, _ = II.channel_from_image(img, 0.5, (80, 20, 20))
 run("staircase 80 x 20 x 20", ms, bcs)

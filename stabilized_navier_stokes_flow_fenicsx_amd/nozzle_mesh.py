@@ -224,7 +224,7 @@ def nozzle_channel_mesh(contour_inner, contour_outer, lc: float, *, x_extrude: f
 
 
 def channel_from_image_bodyfitted(img_fname: str, flowrate_ratio: float, lc: float, *, max_pixels: int | None = 1024,
-                                  cross_size: float | None = None, far: float = 2.0):
+                                  cross_size: float | None = None, far: float = 2.0, x_extrude: float = 0.5):
     """(mesh, (mask, g), inlet profiles) of NavierStokesChannelFlow.py's fine or coarse stage on the body-fitted channel:
     generate_inlet_profiles + generate_mesh + create_boundary_conditions (:102-147).  Dirichlet sets in the reference's order
     [wall, inlet_1, inlet_2, outlet] (:146: later entries win on shared nodes): wall u = 0, inlets u = (profile, 0, 0) by
@@ -232,7 +232,8 @@ def channel_from_image_bodyfitted(img_fname: str, flowrate_ratio: float, lc: flo
     from .bcs import DirichletBC, DirichletSet
     from .inlet_contours import solve_inlet_profiles
     data = solve_inlet_profiles(img_fname, flowrate_ratio, max_pixels=max_pixels)
-    m = nozzle_channel_mesh(data.contour_inner[:, ::-1], data.contour_outer[:, ::-1], lc, cross_size=cross_size, far=far)
+    m = nozzle_channel_mesh(data.contour_inner[:, ::-1], data.contour_outer[:, ::-1], lc, cross_size=cross_size, far=far,
+                            x_extrude=x_extrude)
     t = m.meta["tags"]
     pts = m.points
 
