@@ -134,4 +134,42 @@ def renumbered(m, name):
     return TetMesh(p[order], new[m.tets].astype(np.int32), m.facets, m.facet_tags, name=name, meta={})
 run("(f) = (d) with the nodes renumbered so that the cells' common diagonal runs towards increasing ids", renumbered(square_prism_duct(h, True), "renumbered"))
 run("(g) = (b) with the nodes renumbered the same way", renumbered(hex_prism_duct(h), "renumbered hex"))
+def strips_duct(h):
+    # (h) the body-fitted nozzle channel's OWN mesh type without its flow: the cross-section that conforms to the image's two contours
+    # (square lattice + strips of general triangles along them), uniform planes, the nozzle shrunk to the first cell layer; uniform
+    # inflow through both inlets, no-slip on every wall facet
+    from stabilized_navier_stokes_flow_fenicsx_amd import nozzle_mesh as NM
+    from stabilized_navier_stokes_flow_fenicsx_amd.inlet_contours import solve_inlet_profiles
+    img = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "inlet_PlusF_final.png")
+    data = solve_inlet_profiles(img, 0.5, max_pixels=1024)
+    orig = NM.size_along_x
+    NM.size_along_x = lambda x, lc_, x_extrude=0.5, growth=0.35, far=2.0: np.full_like(np.asarray(x, dtype=np.float64), h)
+    try:
+        m = NM.nozzle_channel_mesh(data.contour_inner[:, ::-1], data.contour_outer[:, ::-1], h / 0.75, x_extrude=h, cross_size=h,
+                                   lattice_behind=None)             # (the contours' strips through the whole channel: the first versions)
+    finally:
+        NM.size_along_x = orig
+    return m
+
+def bcs_by_tags(m):
+    t = m.meta["tags"]
+    nd = 4 * m.num_nodes
+    mask, g = np.zeros(nd, np.uint8), np.zeros(nd)
+    wall = m.facet_nodes(t["wall"])
+    inlet = np.setdiff1d(np.union1d(m.facet_nodes(t["inlet_1"]), m.facet_nodes(t["inlet_2"])), wall)
+    for c in range(3):
+        mask[4 * np.union1d(wall, inlet) + c] = 1
+    g[4 * inlet] = 1.0
+    mask[4 * m.facet_nodes(t["outlet"]) + 3] = 1
+    return mask, g
+
+def run_tags(name, m):
+    P = FlowProblem(m, bcs_by_tags(m), reynolds=50.0)
+    U, r = P.stokes_solve(); w, nn = P.newton_solve(U.clone())
+    rows = [hh["rows"] for hh in P.hierarchy()]
+    P.close()
+    print(f"{name}: max dihedral per cell 50 / 90 / 100 %: {max_dihedral(m)};  {m.num_tets} tets, {m.num_nodes} nodes, stokes {r.its}, newton {nn.its} its {nn.ksp_its} ksp "
+          f"({nn.ksp_its / nn.its:.1f}/step) reason {nn.reason}; rows {rows} ratios {[round(rows[i] / rows[i + 1], 2) for i in range(len(rows) - 1)]}", flush=True)
+
+run_tags("(h) the nozzle channel's cross-section (square lattice + contour strips), uniform planes, nozzle one cell long, plain inflow", strips_duct(h))
 run("(e) the same cross-section, prisms cut in plain (y, x) order", square_prism_duct(h, False))

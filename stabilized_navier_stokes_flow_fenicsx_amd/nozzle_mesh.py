@@ -18,10 +18,16 @@ geometry is an EXTRUSION, which allows an exactly conforming construction from w
   3. prisms over the fluid triangles for x < x_extrude (the band is left out: no node exists inside the wall) and over all
      triangles beyond, each cut into three tets along diagonals that are fixed by the vertex ids, so that neighbours agree.
 The nozzle surfaces are therefore the contour polygons themselves, extruded -- the same surfaces the reference hands to
-gmsh --, the lip at x_extrude is a mesh plane, and the cells are well shaped (no slivers).  Difference to the reference's
-meshes, stated: the cross-section triangulation is the same on every plane (size 0.75 lc everywhere in y, z), so the cells
-are elongated in x (aspect 2.7) where the reference coarsens isotropically to 2 lc, and flattened (0.5) around the lip.
-The aggregation of the AMG hierarchy keeps to the short edges on such meshes (csrc/sns_host.cpp: aggregate_nodes).
+gmsh --, and the lip at x_extrude is a mesh plane.
+  4. (second version) Behind the lip nothing needs the contours: from 0.15 behind it on the cross-section is the contour-free
+     square lattice of the same spacing, and from where the planes lie more than 1.8 cells apart (the reference's far field,
+     2 lc) the lattice of twice the spacing (1.5 lc in y, z: still finer than the reference's 2 lc), each change of
+     cross-section through ONE layer of general tets (transition_slab: the 3-D Delaunay cells of the two planes' points,
+     whose faces in either plane are that plane's triangles -- checked).  Away from the contours every prism is a Kuhn cell
+     (right-triangle base, cut so that no dihedral angle exceeds 90 degrees) and the nodes are numbered along the cells' common
+     diagonal: what the aggregation AMG needs (profiles/r5_prism_vs_kuhn.txt).
+Difference to the reference's meshes, stated: in front of the far field the cross-section's size is 0.75 lc everywhere in
+y, z, so the cells are flattened in x (0.5) around the lip where the reference refines isotropically to 0.375 lc.
 """
 from __future__ import annotations
 
@@ -166,8 +172,64 @@ def cross_section(contour_inner, contour_outer, h2: float, lattice: str = "squar
     return pts, tris, region, chains[0], chains[1]
 
 
+def lattice_section(nx: int):
+    """The contour-free cross-section: the full square lattice of [-.5, .5]^2 with nx cells a side, every cell cut along the
+    diagonal from (y + 1, z) to (y, z + 1), points numbered by (z ascending, y descending) -- the interior of ``cross_section``'s
+    square lattice continued up to the contours' place.  Returns (points (n, 2), tris (e, 3))."""
+    jj, ii = np.meshgrid(np.arange(nx + 1), np.arange(nx + 1), indexing="ij")
+    pts = np.stack([-0.5 + ii / nx, -0.5 + jj / nx], axis=-1).reshape(-1, 2)
+    order = np.lexsort((-np.round(pts[:, 0], 12), np.round(pts[:, 1], 12)))
+    new = np.empty(len(pts), dtype=np.int64)
+    new[order] = np.arange(len(pts))
+    node = lambda i, j: new[j * (nx + 1) + i]
+    i, j = np.meshgrid(np.arange(nx), np.arange(nx), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    tris = np.concatenate([np.stack([node(i + 1, j), node(i, j), node(i, j + 1)], axis=1),
+                           np.stack([node(i + 1, j), node(i + 1, j + 1), node(i, j + 1)], axis=1)])
+    return pts[order], tris.astype(np.int64)
+
+
+def transition_slab(p_bot, t_bot, x_bot: float, p_top, t_top, x_top: float, h2: float):
+    """Tets of the one layer between two DIFFERENT cross-sections (both Delaunay triangulations of their points under the shear
+    of ``cross_section``): the 3-D Delaunay tetrahedralisation of the two planes' points.  Its faces in either plane are the
+    2-D Delaunay triangles of that plane's points, i.e. the layer conforms to the prisms below and above -- checked, not assumed.
+    qhull sees the points through a linear map close to the identity (the in-plane shear that decides the lattice cells'
+    diagonals, and the upper plane shifted by a few per cent of a cell, so that no eight lattice points are cospherical): the
+    result is a valid triangulation of the true points, only not exactly their Delaunay one.  Returns (tets (e, 4) with bottom
+    nodes 0..nb-1 and top nodes nb.., smallest cell volume / mean cell volume)."""
+    from scipy.spatial import Delaunay
+    nb, nt = len(p_bot), len(p_top)
+    P = np.zeros((nb + nt, 3))
+    P[:nb, 0], P[:nb, 1:] = x_bot, p_bot
+    P[nb:, 0], P[nb:, 1:] = x_top, p_top
+    Q = P.copy()
+    Q[:, 1] += 1e-4 * P[:, 2]
+    Q[nb:, 1] += 0.031 * h2
+    Q[nb:, 2] += 0.017 * h2
+    T = Delaunay(Q).simplices.astype(np.int64)
+    nbot = (T < nb).sum(axis=1)
+    if ((nbot == 0) | (nbot == 4)).any():
+        raise ValueError("transition layer: a cell lies in one plane")
+    vol = np.einsum("ij,ij->i", np.cross(P[T[:, 1]] - P[T[:, 0]], P[T[:, 2]] - P[T[:, 0]]), P[T[:, 3]] - P[T[:, 0]]) / 6.0
+    T[vol < 0] = T[vol < 0][:, [0, 2, 1, 3]]
+    vol = np.abs(vol)
+    if abs(vol.sum() - (x_top - x_bot)) > 1e-9:
+        raise ValueError("transition layer: the cells do not fill the slab")
+
+    def plane_faces(sel_count, lower):
+        t = np.sort(T[nbot == sel_count], axis=1)              # three nodes of one plane + one of the other
+        f = t[:, :3] if lower else t[:, 1:] - nb
+        return np.unique(f, axis=0)
+
+    if not (np.array_equal(plane_faces(3, True), np.unique(np.sort(t_bot, axis=1), axis=0)) and
+            np.array_equal(plane_faces(1, False), np.unique(np.sort(t_top, axis=1), axis=0))):
+        raise ValueError("transition layer: its faces are not the cross-sections' triangles")
+    return T, float(vol.min() / vol.mean())
+
+
 def nozzle_channel_mesh(contour_inner, contour_outer, lc: float, *, x_extrude: float = 0.5, x_outlet: float = 4.0,
-                        cross_size: float | None = None, far: float = 2.0) -> TetMesh:
+                        cross_size: float | None = None, far: float = 2.0, lattice_behind: float | None = 0.15,
+                        coarse_far_field: bool = True) -> TetMesh:
     """The body-fitted channel (module docstring).  contour_* are (m, 2) polygons in (y, z); lc is the reference's
     ``channel_mesh_size`` (NavierStokesChannelFlow.py:81-93); the cross-section is triangulated at ``cross_size``
     (default 0.75 lc: what the reference's inlet region gets -- min of the points' lc and the first Box field's 0.75 lc,
@@ -181,22 +243,67 @@ def nozzle_channel_mesh(contour_inner, contour_outer, lc: float, *, x_extrude: f
     fluid_tri = region != 0
     fluid_node = np.zeros(n2, dtype=bool)
     fluid_node[tris[fluid_tri].ravel()] = True
+    # Behind the lip nothing needs the contours, and the strips of general triangles along them cost Krylov iterations as long as
+    # they run (profiles/r5_prism_vs_kuhn.txt, case (h): 1.5x on a plain inflow): from the first plane at least `lattice_behind`
+    # behind the lip on, the cross-section is the contour-free lattice of the same spacing; and from where the planes lie more
+    # than 1.8 cross-section cells apart (the reference's far field, 2 lc, :445-483) the lattice of TWICE the spacing (1.5 lc: still
+    # finer than the reference's far field), so that the far-field cells are not stretched.  ONE layer of general tets joins two
+    # different cross-sections (transition_slab); a transition that cannot be made well leaves the cross-section as it is.
+    nx = max(2, int(round(1.0 / h2)))
+    sections = [(p2, tris)]                                      # (points, triangles) of the cross-sections, in the order they appear
+    sec_of = np.zeros(nl, dtype=np.int64)                        # plane -> cross-section
+    slabs = {}                                                   # lower plane of a transition layer -> its tets
+    quality = []
+    if lattice_behind is not None:
+        wanted = [(lattice_section(nx), np.nonzero(xs >= x_extrude + float(lattice_behind) - 1e-12)[0])]
+        if coarse_far_field and nx >= 8:
+            dx = np.diff(xs)
+            wanted.append((lattice_section((nx + 1) // 2), np.nonzero(dx >= 1.8 / nx)[0]))
+        k_prev = k_lip
+        for (pS, tS), cand in wanted:
+            cand = cand[(cand > k_prev) & (cand < nl - 2)]
+            if not len(cand):
+                break
+            k = int(cand[0])
+            pL, tL = sections[-1]
+            try:
+                slab, q = transition_slab(pL, tL, xs[k], pS, tS, xs[k + 1], h2)
+            except ValueError:
+                break
+            if q < 1e-3:                                         # (a sliver thinner than 1/1000 of the mean cell: keep the section)
+                break
+            sections.append((pS, tS))
+            sec_of[k + 1:] = len(sections) - 1
+            slabs[k] = slab
+            quality.append(q)
+            k_prev = k + 1
     # node numbering: plane by plane; planes upstream of the lip hold the fluid nodes only (nothing exists inside the wall)
-    ids = -np.ones((nl, n2), dtype=np.int64)
+    width = max(len(ps) for ps, _ in sections)
+    ids = -np.ones((nl, width), dtype=np.int64)
     count = 0
     for k in range(nl):
-        sel = fluid_node if k < k_lip else np.ones(n2, dtype=bool)
+        n_k = len(sections[sec_of[k]][0])
+        sel = np.zeros(width, dtype=bool)
+        sel[:n_k] = fluid_node if (k < k_lip and sec_of[k] == 0) else True
         ids[k, sel] = count + np.arange(int(sel.sum()))
         count += int(sel.sum())
     pts = np.zeros((count, 3))
     for k in range(nl):
-        sel = ids[k] >= 0
-        pts[ids[k, sel], 0] = xs[k]
-        pts[ids[k, sel], 1:] = p2[sel]
-    ts = np.sort(tris, axis=1)                                   # v0 < v1 < v2: the diagonals of the quads follow the ids
+        ps = sections[sec_of[k]][0]
+        sel = ids[k, :len(ps)] >= 0
+        pts[ids[k, :len(ps)][sel], 0] = xs[k]
+        pts[ids[k, :len(ps)][sel], 1:] = ps[sel]
+    sorted_tris = [np.sort(ts_, axis=1) for _, ts_ in sections]  # v0 < v1 < v2: the diagonals of the quads follow the ids
     tets = []
     for k in range(nl - 1):
-        t = ts[fluid_tri] if k < k_lip else ts
+        if k in slabs:                                           # the one layer of general tets between two cross-sections
+            nb_, nt_ = len(sections[sec_of[k]][0]), len(sections[sec_of[k + 1]][0])
+            both = np.concatenate([ids[k, :nb_], ids[k + 1, :nt_]])
+            tets.append(both[slabs[k]])
+            continue
+        t = sorted_tris[sec_of[k]]
+        if k < k_lip and sec_of[k] == 0:
+            t = t[fluid_tri]
         b0, b1, b2 = ids[k, t[:, 0]], ids[k, t[:, 1]], ids[k, t[:, 2]]
         w0, w1, w2 = ids[k + 1, t[:, 0]], ids[k + 1, t[:, 1]], ids[k + 1, t[:, 2]]
         tets.append(np.concatenate([np.stack([b0, b1, b2, w2], axis=1), np.stack([b0, b1, w2, w1], axis=1),
@@ -219,7 +326,10 @@ def nozzle_channel_mesh(contour_inner, contour_outer, lc: float, *, x_extrude: f
     ftags[on_x & (np.abs(cen[:, 0] - x_outlet) < 1e-9)] = T["outlet"]
     meta = {"kind": "channel-nozzle", "tags": dict(T), "lc": float(lc), "cross_size": h2, "x_extrude": float(x_extrude),
             "planes": int(nl), "lip_plane": k_lip, "cross_section_nodes": int(n2), "cross_section_triangles": int(len(tris)),
-            "band_triangles": int((~fluid_tri).sum())}
+            "band_triangles": int((~fluid_tri).sum()),
+            "transition_planes": sorted(int(k) for k in slabs), "transition_x": [float(xs[k]) for k in sorted(slabs)],
+            "transition_smallest_cell": [float(q) for q in quality],
+            "cross_sections": [{"nodes": int(len(ps)), "triangles": int(len(ts_))} for ps, ts_ in sections]}
     return TetMesh(pts, tets.astype(np.int32), facets.astype(np.int32), ftags, name="nozzle-channel", meta=meta)
 
 

@@ -742,6 +742,31 @@ def test_bodyfitted_nozzle_channel_geometry(name):
     # (each stretch is rescaled to end on its plane: up to +30 % on the handful of planes upstream of the lip)
     assert dx[mid < 0.25].max() < 1.0 * lc and dx[(mid > 0.4) & (mid < 0.6)].max() < 0.5 * lc        # 0.75 lc, 0.375 lc
     assert dx[(mid > 0.75) & (mid < 1.0)].max() < 0.65 * lc and 1.5 * lc < dx[mid > 2.5].max() <= 2.2 * lc   # lc / 2, 2 lc
+    # behind the lip the cross-section changes twice -- contour-free lattice, then the lattice of twice the spacing where the planes
+    # lie far apart --, each time through one layer of general tets that conforms on both sides (the volume and area sums above
+    # would show a hole or an overlap) and holds no sliver
+    tp, tx = m.meta["transition_planes"], m.meta["transition_x"]
+    cs = m.meta["cross_sections"]
+    assert len(tp) == 2 and 0.5 + 0.15 - 1e-9 <= tx[0] < 0.5 + 0.15 + lc and tx[1] > tx[0] and len(cs) == 3
+    assert cs[2]["nodes"] < 0.3 * cs[1]["nodes"] and abs(cs[1]["nodes"] - cs[0]["nodes"]) < 0.1 * cs[0]["nodes"]
+    assert min(m.meta["transition_smallest_cell"]) > 1e-3
+    npl = np.array([np.sum(np.abs(m.points[:, 0] - x) < 1e-12) for x in xs])
+    assert npl[-1] == cs[2]["nodes"] and npl[np.searchsorted(xs, tx[0]) + 1] == cs[1]["nodes"]
+    far = m.points[:, 0] > tx[1] + 2.5 * lc                                           # far field: a lattice, every prism a Kuhn cell
+    tets_far = m.tets[far[m.tets].all(axis=1)]
+    P4 = m.points[tets_far]
+    import itertools
+    worst = np.zeros(len(tets_far))
+    for (i, j) in itertools.combinations(range(4), 2):
+        k, l = [q for q in range(4) if q not in (i, j)]
+        e = P4[:, j] - P4[:, i]
+        e /= np.linalg.norm(e, axis=1)[:, None]
+        a_ = P4[:, k] - P4[:, i]
+        a_ -= (a_ * e).sum(1)[:, None] * e
+        b_ = P4[:, l] - P4[:, i]
+        b_ -= (b_ * e).sum(1)[:, None] * e
+        worst = np.maximum(worst, np.degrees(np.arccos(np.clip((a_ * b_).sum(1) / np.linalg.norm(a_, axis=1) / np.linalg.norm(b_, axis=1), -1, 1))))
+    assert len(tets_far) > 1000 and worst.max() < 90.0 + 1e-6                        # no obtuse dihedral angle in the far field
     # Dirichlet sets in the reference's order [wall, inlet_1, inlet_2, outlet]; the inlet data carry ratio : 1 - ratio
     q1, q2, _ = NM.inlet_fluxes(m, g)
     # (lc = 0.06, cross-section size 0.045: the P1 interpolant of the Poisson profiles on a few hundred inlet triangles, as coarse as
