@@ -373,9 +373,11 @@ def host_problem(cfg, cells, length, inlet="image"):
         img = os.path.join(ROOT, "tests", "golden", "inlet_PlusF_final.png")
         lc = cells[0] / 1000.0
         mesh, bcs, _ = NM.channel_from_image_bodyfitted(img, 0.5, lc)
+        secs = " / ".join(str(c["triangles"]) for c in mesh.meta.get("cross_sections", [{"triangles": mesh.meta["cross_section_triangles"]}]))
         return mesh, bcs, (f"channel 4x1x1 minus the nozzle wall of the reference's Plus image extruded over x in [0, 0.5] (body-fitted, "
-                           f"channel_mesh_size {lc:g}: {mesh.meta['planes']} node planes x {mesh.meta['cross_section_triangles']} cross-section "
-                           "triangles), inlet profiles from the image, flowrate ratio 0.5")
+                           f"channel_mesh_size {lc:g}: {mesh.meta['planes']} node planes; cross-sections of {secs} triangles: contour-conforming "
+                           "up to 0.15 behind the lip, contour-free lattice, the lattice of twice the spacing in the far field), "
+                           "inlet profiles from the image, flowrate ratio 0.5")
     if cfg == "4u":                        # the reference's production meshes are gmsh Delaunay (image2gmsh3D.py:445-486)
         mesh = M.delaunay_channel_mesh(cells[0], lattice="bcc")
         return (mesh, B.channel_bcs(mesh, *B.two_stream_profiles(0.5)).flatten(),
