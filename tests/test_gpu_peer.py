@@ -72,6 +72,9 @@ def _run_ranks(kind, world, tmp_path, env_extra=None, deadline=420.0):
 
 
 @pytest.mark.parametrize("kind,world,opts", [("duct", 3, None), ("duct-rep-dense", 3, None), ("cavity", 4, None),
+                                             # five ranks: an RCB partition that is not a power of two (with this process the six
+                                             # GPU processes a box admits)
+                                             ("cavity", 5, None),
                                              # round 4's form of the exchange (put + wait / unpack into the ghost tail, interior rows on
                                              # a second stream meanwhile): what RCCL-shaped code paths and halo_windows = 0 run
                                              ("cavity", 4, {"halo_windows": 0, "amg_exact_sweeps": 0})])
@@ -94,7 +97,8 @@ def test_partitioned_solve_between_processes_over_peer_windows(kind, world, opts
     if kind == "duct-rep-dense":
         assert r0["levels"] == 2                               # fine level + the replicated, directly solved level 1
     if kind == "cavity":
-        assert max(len(r["neighbors"]) for r in res) == 3
+        most = max(len(r["neighbors"]) for r in res)
+        assert most == 3 if world == 4 else most >= 3
 
 
 def test_carried_puts_match_separate_put_launches_between_processes(tmp_path):
