@@ -30,6 +30,11 @@ GHAT = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0
 
 _T = torch.float64
 
+# Perturbations of the stabilisation for the study of what the reference-held constants tell apart (round 5, DESIGN.md section 5;
+# the product's sns_set_form_variant): C_I of :237, a factor on the LSIC coefficient of :249, the sign of the PSPG part of the test
+# function of :247, and all four quadrature points moved to the centroid (a 1-point rule).  The defaults ARE the reference's form.
+VARIANT = dict(ci=36.0, lsic=1.0, pspg=1.0, one_point=False)
+
 
 def _phi(xi):
     return torch.stack([1.0 - xi[0] - xi[1] - xi[2], xi[0], xi[1], xi[2]])
@@ -61,7 +66,7 @@ def ns_residual_literal(X, w, Re, *, corrected_convection: bool = False):
     dxi_dy = K
     dxi_dx = dxi_dy @ torch.linalg.inv(torch.eye(3, dtype=_T))
     G = dxi_dx.T @ dxi_dx
-    Ci = 36.0                                                            # :237
+    Ci = VARIANT["ci"]                                                    # :237 (36)
     grad_u = torch.einsum("ai,aj->ij", U, gphi)                          # grad(u)[i,j] = du_i/dx_j
     nabla_grad_u = grad_u.T
     div_u = torch.trace(grad_u)
@@ -70,7 +75,7 @@ def ns_residual_literal(X, w, Re, *, corrected_convection: bool = False):
     out = torch.zeros(16, dtype=_T)
     res = []
     for q in range(4):
-        phi = _phi(torch.as_tensor(QPTS[q], dtype=_T))
+        phi = _phi(torch.as_tensor([0.25, 0.25, 0.25] if VARIANT["one_point"] else QPTS[q], dtype=_T))
         u = torch.einsum("a,ai->i", phi, U)
         p = torch.dot(phi, P)
         tau = 1.0 / torch.sqrt(torch.dot(u, G @ u) + Ci * nu ** 2 * torch.sum(G * G))   # :238
@@ -81,7 +86,7 @@ def ns_residual_literal(X, w, Re, *, corrected_convection: bool = False):
             res_M = u @ nabla_grad_u - div_sigma
         else:
             res_M = u @ grad_u - div_sigma                               # dot(u, grad(u)) :241
-        v_lsic = 1.0 / (torch.trace(G) * tau)                            # :249
+        v_lsic = VARIANT["lsic"] / (torch.trace(G) * tau)                # :249
         wq = QW[q] * detJ
         vals = []
         for a in range(4):
@@ -102,7 +107,7 @@ def ns_residual_literal(X, w, Re, *, corrected_convection: bool = False):
                 t = t + nu * torch.sum(grad_u * grad_v)                  # :244
                 t = t - p * div_v                                        # :245
                 t = t + qt * div_u                                       # :246
-                supg_test = (u @ nabla_grad(grad_v) if corrected_convection else u @ grad_v) + grad_q
+                supg_test = (u @ nabla_grad(grad_v) if corrected_convection else u @ grad_v) + VARIANT["pspg"] * grad_q
                 t = t + torch.dot(tau * res_M, supg_test)                # :247
                 t = t + v_lsic * div_v * div_u                           # :251
                 vals.append(wq * t)

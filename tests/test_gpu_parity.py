@@ -39,6 +39,43 @@ def test_native_library_is_loaded(gpu):
     assert "libsns.so" in open("/proc/self/maps").read() or "libsns.so" in maps
 
 
+def test_perturbed_forms_are_what_they_say(gpu):
+    """Round 5: sns_set_form_variant (C_I, LSIC factor, PSPG sign, 1-point quadrature -- the perturbations behind the table of what
+    the DFG constants tell apart) against the SAME perturbation of the literal restatement
+    (oracle/forms_literal.VARIANT, Jacobian by autograd): element residual and Jacobian on the golden tets to 1e-12, so that the
+    table's rows are statements about the forms they name."""
+    from oracle import forms_literal as FL
+    from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M
+    g = golden("element_ns.npz")
+    none = (np.zeros(16, np.uint8), np.zeros(16))
+    base = dict(FL.VARIANT)
+    cases = (dict(ci=4.0), dict(ci=0.0), dict(lsic=0.0), dict(lsic=4.0), dict(pspg=-1.0), dict(one_point=True),
+             dict(ci=144.0, lsic=4.0, pspg=-1.0, one_point=True))
+    try:
+        for i in range(min(3, len(g["X"]))):
+            m = M.TetMesh(g["X"][i].copy(), np.array([[0, 1, 2, 3]], np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
+            for kw in cases:
+                FL.VARIANT.update(base)
+                FL.VARIANT.update(kw)
+                Fo, Jo = FL.ns_residual_and_jacobian_literal(g["X"][i], g["W"][i].reshape(16), float(g["Re"][i]))
+                P = gpu(m, none, reynolds=float(g["Re"][i]), pc_type="bjacobi", assembly_fused=0)
+                P.set_form_variant(c_inverse=FL.VARIANT["ci"], lsic_scale=FL.VARIANT["lsic"], pspg_sign=FL.VARIANT["pspg"],
+                                   one_point_quadrature=FL.VARIANT["one_point"])
+                F = P.zeros()
+                P.jacobian(_dev(g["W"][i].reshape(16)), "ns", residual_out=F)
+                Ke = P.element_matrices().cpu().numpy()[0]
+                assert rel(Ke.transpose(0, 2, 1, 3).reshape(16, 16), Jo) < 1e-12, kw
+                assert rel(F.cpu().numpy(), Fo) < 1e-12, kw
+                assert rel(P.to_scipy().toarray(), Jo) < 1e-12, kw                        # what the solver is handed
+                P.close()
+        # ... and the defaults are the reference's form: the golden vectors themselves
+        FL.VARIANT.update(base)
+        Fo, Jo = FL.ns_residual_and_jacobian_literal(g["X"][0], g["W"][0].reshape(16), float(g["Re"][0]))
+        assert rel(Jo, g["J"][0]) < 1e-14 and rel(Fo, g["F"][0]) < 1e-14
+    finally:
+        FL.VARIANT.update(base)
+
+
 def test_element_kernel_against_golden_literal_forms(gpu):
     """Each golden tet as a one-tet mesh: element Jacobian/residual vs the literal UFL restatement."""
     from stabilized_navier_stokes_flow_fenicsx_amd import mesh as M
