@@ -203,6 +203,40 @@ def test_host_aggregation_covers_and_limits(built_lib):
     assert np.array_equal(agg, agg3)                                           # deterministic
 
 
+def test_transition_layer_between_two_cross_sections():
+    """nozzle_mesh.transition_slab: the one layer of general tets between two different cross-sections conforms to both (its faces in
+    either plane are that plane's triangles), fills the slab, holds no sliver between nested lattices -- and says so (ValueError)
+    when a cross-section's triangles are not the Delaunay ones, which is what lets the mesher keep the old cross-section instead."""
+    from stabilized_navier_stokes_flow_fenicsx_amd import nozzle_mesh as NM
+    pa, ta = NM.lattice_section(8)
+    pb, tb = NM.lattice_section(4)
+    # every lattice triangle is a right triangle whose right angle sits at its MIDDLE vertex (what makes its prism three Kuhn cells)
+    for p, t in ((pa, ta), (pb, tb)):
+        v = p[np.sort(t, axis=1)]
+        assert np.abs(((v[:, 0] - v[:, 1]) * (v[:, 2] - v[:, 1])).sum(axis=1)).max() < 1e-14
+        e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+        assert abs(0.5 * np.abs(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]).sum() - 1.0) < 1e-12
+    T, q = NM.transition_slab(pa, ta, 1.0, pb, tb, 1.125, 0.125)
+    P = np.zeros((len(pa) + len(pb), 3))
+    P[:len(pa), 0], P[:len(pa), 1:], P[len(pa):, 0], P[len(pa):, 1:] = 1.0, pa, 1.125, pb
+    vol = np.einsum("ij,ij->i", np.cross(P[T[:, 1]] - P[T[:, 0]], P[T[:, 2]] - P[T[:, 0]]), P[T[:, 3]] - P[T[:, 0]]) / 6.0
+    assert vol.min() > 0 and abs(vol.sum() - 0.125) < 1e-12 and q > 0.3
+    nbot = (T < len(pa)).sum(axis=1)
+    assert set(np.unique(nbot)) <= {1, 2, 3}
+    bottom = {tuple(sorted(t[t < len(pa)])) for t in T[nbot == 3]}
+    assert bottom == {tuple(sorted(t)) for t in ta}
+    # a cross-section whose diagonals are not the ones the shear selects is refused
+    bad = ta.copy()
+    quad = set(bad[0]) | set(bad[len(bad) // 2])                                  # the two triangles of cell (0, 0)
+    shared = sorted(set(bad[0]) & set(bad[len(bad) // 2]))
+    others = sorted(quad - set(shared))
+    assert len(shared) == 2 and len(others) == 2
+    bad[0] = [others[0], others[1], shared[0]]
+    bad[len(bad) // 2] = [others[0], others[1], shared[1]]
+    with pytest.raises(ValueError):
+        NM.transition_slab(pa, bad, 1.0, pb, tb, 1.125, 0.125)
+
+
 def test_aggregation_does_not_depend_on_the_node_numbering(built_lib):
     """Round 5 (profiles/r5_prism_vs_kuhn.txt): the greedy sweep takes the free neighbours AHEAD of its front.  On a Kuhn lattice
     numbered along the cells' common diagonal those are the seven other corners of a cube; on the same lattice numbered against it
